@@ -1,0 +1,53 @@
+"""Build libfs3d_hip.so (the C-ABI library of include/fs3d.h) for gfx950 with hipcc.
+
+In-tree build: the .so lands next to this file so that it travels to the GPU box
+with the repo snapshot.  hipcc cross-compiles without a GPU.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libfs3d_hip.so")
+SOURCES = ["fs3d_hip.hip", "fs3d_comm.hip", "kernels_line.hip", "kernels_pipe.hip"]
+HEADERS = ["fs3d_common.h", "fs3d_rows.h", "fs3d_comm.h", os.path.join("..", "..", "include", "fs3d.h")]
+
+# -ffp-contract=off: no FMA contraction, the reference's CPU path rounds after every operation.
+# -fhip-fp32-correctly-rounded-divide-sqrt: IEEE fp32 division (the hipcc default, stated explicitly).
+# no -ffast-math, denormals preserved (hipcc default).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+         "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    objs = []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(CSRC, s.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _stale(obj, [src] + hdrs):
+            cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+    if force or _stale(LIB, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + \
+              ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,90 @@
+// Shared declarations of the HIP implementation behind include/fs3d.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/fs3d.h"
+
+// ---- per-cell code word (uint16) ------------------------------------------------
+// bits 0..3   row code of the X sweep
+// bits 4..7   row code of the Y sweep
+// bits 8..11  row code of the Z sweep
+// bits 12..13 NodeType (Geometry.h:31-36)
+// row code: bits 0..1 kind, bit 2 velocity BC is FREE, bit 3 temperature BC is FREE
+// (BC bits are only meaningful for START/END rows).
+// The kinds restate Grid3D::GenerateListSegments (Grid3D.cpp:47-127) per cell: a
+// segment is START, INTERIOR.., END along its line; everything else is SKIP.
+enum { ROW_SKIP = 0, ROW_INTERIOR = 1, ROW_START = 2, ROW_END = 3 };
+#define ROW_VELFREE 4
+#define ROW_TEMPFREE 8
+#define CODE_TYPE_SHIFT 12
+
+template <typename R>
+struct SweepParams {
+    // geometry
+    int dimx, dimy, dimz;       // owned planes
+    long long plane;            // dimy*dimz
+    // layers: 4 fields each, pointers to the first OWNED cell (one halo plane precedes)
+    const R *cur[4];
+    const R *temp[4];           // temp read by the stencils (old temp)
+    R *next[4];
+    R *temp_out[4];             // merged temp (== temp buffers when not double-buffered)
+    const uint16_t *code;
+    const R *node[4];           // node boundary values (v.x, v.y, v.z, T)
+    R *scr[6];                  // LINE kernel scratch: c'_uvw, c'_T, d'_U, d'_V, d'_W, d'_T
+    // constants, all rounded exactly as the reference's FTYPE expressions
+    R two_ds[3];                // 2*dx, 2*dy, 2*dz            (TimeLayer3D.h:338-340)
+    R vis_v, vis_t;             // v_vis/(ds*ds), t_vis/(ds*ds) (AdiSolver3D.cpp:744-751) for the sweep axis
+    R b_v, b_t;                 // 3/dt + 2*vis                 (AdiSolver3D.cpp:761)
+    R dt;
+    R v_T, t_phi;
+    int merge;                  // 0: write next only; 1: also temp_out = merged; 2: merged twice (sweep merge + global merge)
+};
+
+struct fs3d_ctx {
+    int device = 0;
+    fs3d_precision prec = FS3D_F32;
+    int dimx = 0, dimy = 0, dimz = 0, x_offset = 0, dimx_global = 0;
+    double gdx = 0, gdy = 0, gdz = 0;
+    double v_T = 1, v_vis = 0, t_vis = 0, t_phi = 0;
+    bool have_params = false, have_nodes = false;
+    size_t esize = 4;
+    long long plane = 0, ncell = 0;
+    // 5 layer buffers (cur,temp,half,next + spare temp for double-buffering); [buf][var] = base alloc (with halos)
+    void *lay[5][4] = {};
+    int slot[4] = {0, 1, 2, 3}; // layer id -> buffer
+    int spare = 4;
+    uint16_t *code = nullptr;
+    void *node[4] = {};
+    void *scr[6] = {};
+    // compact list of NODE_BOUND / NODE_VALVE cells (AdiSolver3D.cpp:286-311)
+    int *bnd_idx = nullptr;
+    void *bnd_val[4] = {};
+    int n_bnd = 0;
+    int nseg[3] = {0, 0, 0};
+    // div error partials
+    double *red_buf = nullptr;     // device
+    double *red_host = nullptr;    // pinned
+    int red_blocks = 0;
+    double diffError = 0.0;
+    hipStream_t stream = nullptr;
+    // options
+    int opt_kernel = FS3D_SWEEP_AUTO;
+    int opt_fuse = 1;
+    // timing
+    bool timing = false;
+    std::vector<hipEvent_t> ev;
+    std::vector<int> ev_class;
+    float t_ms[4] = {0, 0, 0, 0};
+    int t_n[4] = {0, 0, 0, 0};
+    // comm
+    void *comm = nullptr;          // ncclComm_t
+    int rank = 0, nranks = 1;
+    std::string err;
+};
+
+// kernels_*.hip
+template <typename R> void launch_sweep_line(fs3d_ctx *c, int dir, const SweepParams<R> &p);
+template <typename R> bool launch_sweep_pipe(fs3d_ctx *c, int dir, const SweepParams<R> &p); // false: dims unsupported

@@ -1,0 +1,782 @@
+// libfs3d_hip.so -- C ABI (include/fs3d.h) of the MI355X-native FluidSolver3D hot path:
+// context, geometry tables, auxiliary kernels and the time-step orchestration.
+// The line-sweep kernels live in kernels_line.hip / kernels_pipe.hip.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include "fs3d_common.h"
+#include "fs3d_comm.h"
+
+#define FS3D_VERSION "fs3d-hip 0.1 (gfx950)"
+static thread_local std::string g_create_err;
+
+static fs3d_status fail(fs3d_ctx *c, fs3d_status st, const std::string &msg)
+{
+    if (c) c->err = msg; else g_create_err = msg;
+    return st;
+}
+
+// gpuSafeCall (GPUplan.cpp:173-193): message carries the device id and the runtime's error text
+#define HIPCHK(c, call)                                                                              \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess) {                                                                      \
+            char b_[512];                                                                            \
+            snprintf(b_, sizeof b_, "GPU %d: %s failed: %s", (c) ? (c)->device : -1, #call,          \
+                     hipGetErrorString(e_));                                                         \
+            return fail((c), FS3D_ERR_HIP, b_);                                                      \
+        }                                                                                            \
+    } while (0)
+
+// ---------------------------------------------------------------------------------
+// auxiliary kernels
+// ---------------------------------------------------------------------------------
+
+// TimeLayer3D::MergeLayerTo(grid, dest, NODE_IN) (TimeLayer3D.h:415-436, 664-683;
+// GPU twin `merge`, TimeLayer3D.cu:133-146), all four fields in one pass.
+template <typename R>
+__global__ void __launch_bounds__(256) k_merge(const uint16_t *__restrict__ code, long long n,
+                                                const R *s0, const R *s1, const R *s2, const R *s3,
+                                                R *d0, R *d1, R *d2, R *d3)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        if (((code[i] >> CODE_TYPE_SHIFT) & 3) == FS3D_NODE_IN) {
+            d0[i] = (d0[i] + s0[i]) / R(2);
+            d1[i] = (d1[i] + s1[i]) / R(2);
+            d2[i] = (d2[i] + s2[i]) / R(2);
+            d3[i] = (d3[i] + s3[i]) / R(2);
+        }
+    }
+}
+
+// cur->CopyLayerTo(grid, next, NODE_BOUND / NODE_VALVE) (AdiSolver3D.cpp:310-311;
+// TimeLayer3D.h:394-413): the BOUND/VALVE cells are a compact index list here.
+template <typename R>
+__global__ void __launch_bounds__(256) k_copy_list(const int *__restrict__ idx, int n,
+                                                    const R *s0, const R *s1, const R *s2, const R *s3,
+                                                    R *d0, R *d1, R *d2, R *d3)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) { int i = idx[t]; d0[i] = s0[i]; d1[i] = s1[i]; d2[i] = s2[i]; d3[i] = s3[i]; }
+}
+
+// cur->CopyFromGrid(grid, NODE_BOUND / NODE_VALVE) (AdiSolver3D.cpp:292-293;
+// TimeLayer3D.h:926-951): node values of the listed cells, stored compactly.
+template <typename R>
+__global__ void __launch_bounds__(256) k_impose_list(const int *__restrict__ idx, int n,
+                                                      const R *v0, const R *v1, const R *v2, const R *v3,
+                                                      R *d0, R *d1, R *d2, R *d3)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) { int i = idx[t]; d0[i] = v0[t]; d1[i] = v1[t]; d2[i] = v2[t]; d3[i] = v3[t]; }
+}
+
+// TimeLayer3D::Clear(grid, NODE_OUT, MISSING_VALUE x4) (TimeLayer3D.h:974-999; `clear`, TimeLayer3D.cu:98-116)
+template <typename R>
+__global__ void __launch_bounds__(256) k_clear_type(const uint16_t *__restrict__ code, long long n, int type, R val,
+                                                     R *d0, R *d1, R *d2, R *d3)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        if (((code[i] >> CODE_TYPE_SHIFT) & 3) == type) { d0[i] = val; d1[i] = val; d2[i] = val; d3[i] = val; }
+}
+
+// TimeLayer3D::EvalDivError (TimeLayer3D.h:595-641): per-cell FTYPE face sums, double
+// accumulation.  Wave64 shuffle reduction, one partial (sum,count) pair per block;
+// the partials are summed in a fixed order by k_div_final, so the result is
+// run-to-run deterministic (it is NOT the reference's serial summation order: compare
+// with a relative tolerance of ~1e-12).
+template <typename R>
+__global__ void __launch_bounds__(256) k_div_error(const uint16_t *__restrict__ code,
+                                                    const R *__restrict__ U, const R *__restrict__ V,
+                                                    const R *__restrict__ W, int dimx, int dimy, int dimz,
+                                                    int i_end, R dx, R dy, R dz, double *partial)
+{
+    const long long plane = (long long)dimy * dimz;
+    const long long n = (long long)dimx * plane;
+    double err = 0.0, cnt = 0.0;
+    for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < n; id += (long long)gridDim.x * blockDim.x) {
+        const int i = (int)(id / plane);
+        const int rem = (int)(id - (long long)i * plane);
+        const int j = rem / dimz, k = rem - j * dimz;
+        if (i >= i_end || j >= dimy - 1 || k >= dimz - 1) continue;
+        if (((code[id] >> CODE_TYPE_SHIFT) & 3) != FS3D_NODE_IN) continue;
+        if (j == 0 || k == 0) continue;   // reference reads out of bounds there; see oracle note
+        const long long a = id, b = id - dimz, c = id - dimz - 1, d = id - 1;   // (j,k) (j-1,k) (j-1,k-1) (j,k-1)
+        const long long m = plane;
+        const double ex = (double)((U[a] + U[b] + U[c] + U[d] - U[a - m] - U[b - m] - U[c - m] - U[d - m]) * dz * dy) / 4.0;
+        const double ey = (double)((V[a] + V[a - m] + V[d - m] + V[d] - V[b] - V[b - m] - V[c - m] - V[c]) * dx * dz) / 4.0;
+        const double ez = (double)((W[a] + W[b] + W[b - m] + W[a - m] - W[d] - W[c] - W[c - m] - W[d - m]) * dx * dy) / 4.0;
+        err += fabs(ex + ey + ez);
+        cnt += 1.0;
+    }
+    for (int off = 32; off > 0; off >>= 1) { err += __shfl_down(err, off, 64); cnt += __shfl_down(cnt, off, 64); }
+    __shared__ double se[4], sc[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { se[w] = err; sc[w] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[2 * blockIdx.x] = (se[0] + se[1]) + (se[2] + se[3]);
+        partial[2 * blockIdx.x + 1] = (sc[0] + sc[1]) + (sc[2] + sc[3]);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_div_final(const double *partial, int nblocks, double *out)
+{
+    __shared__ double se[256], sc[256];
+    double e = 0.0, c = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 256) { e += partial[2 * b]; c += partial[2 * b + 1]; }
+    se[threadIdx.x] = e; sc[threadIdx.x] = c;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) { se[threadIdx.x] += se[threadIdx.x + s]; sc[threadIdx.x] += sc[threadIdx.x + s]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[0] = se[0]; out[1] = sc[0]; }
+}
+
+// ---------------------------------------------------------------------------------
+// context helpers
+// ---------------------------------------------------------------------------------
+
+template <typename R> static R *fld(fs3d_ctx *c, int buf, int v) { return (R *)c->lay[buf][v] + c->plane; }
+template <typename R> static R *lfld(fs3d_ctx *c, int layer, int v) { return fld<R>(c, c->slot[layer], v); }
+
+static inline unsigned grid_for(long long n, int bs, int cap = 4096)
+{
+    long long g = (n + bs - 1) / bs;
+    return (unsigned)std::max(1LL, std::min<long long>(g, cap));
+}
+
+static void rec_begin(fs3d_ctx *c, int cls)
+{
+    if (!c->timing) return;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0, c->stream);
+    c->ev.push_back(e0); c->ev.push_back(e1); c->ev_class.push_back(cls);
+}
+static void rec_end(fs3d_ctx *c)
+{
+    if (!c->timing) return;
+    hipEventRecord(c->ev.back(), c->stream);
+}
+static void rec_collect(fs3d_ctx *c)
+{
+    for (int k = 0; k < 4; k++) { c->t_ms[k] = 0; c->t_n[k] = 0; }
+    for (size_t i = 0; i < c->ev_class.size(); i++) {
+        float ms = 0;
+        hipEventSynchronize(c->ev[2 * i + 1]);
+        hipEventElapsedTime(&ms, c->ev[2 * i], c->ev[2 * i + 1]);
+        c->t_ms[c->ev_class[i]] += ms; c->t_n[c->ev_class[i]]++;
+        hipEventDestroy(c->ev[2 * i]); hipEventDestroy(c->ev[2 * i + 1]);
+    }
+    c->ev.clear(); c->ev_class.clear();
+}
+
+// ---------------------------------------------------------------------------------
+// lifetime
+// ---------------------------------------------------------------------------------
+
+extern "C" const char *fs3d_version(void) { return FS3D_VERSION; }
+
+extern "C" const char *fs3d_last_error(const fs3d_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+extern "C" fs3d_status fs3d_create(fs3d_ctx **out, int device, fs3d_precision prec, int dimx, int dimy, int dimz,
+                                   double dx, double dy, double dz, int x_offset, int dimx_global)
+{
+    if (!out) return fail(nullptr, FS3D_ERR_INVALID, "fs3d_create: out is NULL");
+    *out = nullptr;
+    if (dimx < 1 || dimy < 3 || dimz < 3 || dimx_global < 3 || x_offset < 0 || x_offset + dimx > dimx_global)
+        return fail(nullptr, FS3D_ERR_INVALID, "fs3d_create: bad dimensions");
+    if (prec != FS3D_F32 && prec != FS3D_F64) return fail(nullptr, FS3D_ERR_INVALID, "fs3d_create: bad precision");
+    if ((long long)(dimx + 2) * dimy * dimz >= (1LL << 31))
+        return fail(nullptr, FS3D_ERR_UNSUPPORTED, "fs3d_create: slab has more than 2^31 cells");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) return fail(nullptr, FS3D_ERR_HIP, "fs3d_create: no HIP device available");
+    if (device < 0 || device >= ndev) return fail(nullptr, FS3D_ERR_INVALID, "fs3d_create: bad device ordinal");
+    fs3d_ctx *c = new fs3d_ctx();
+    c->device = device; c->prec = prec;
+    c->dimx = dimx; c->dimy = dimy; c->dimz = dimz; c->x_offset = x_offset; c->dimx_global = dimx_global;
+    c->gdx = dx; c->gdy = dy; c->gdz = dz;
+    c->esize = prec == FS3D_F32 ? 4 : 8;
+    c->plane = (long long)dimy * dimz; c->ncell = c->plane * dimx;
+#define CK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { char b_[256]; snprintf(b_, sizeof b_, "GPU %d: %s failed: %s", device, #call, hipGetErrorString(e_)); g_create_err = b_; fs3d_destroy(c); return FS3D_ERR_HIP; } } while (0)
+    CK(hipSetDevice(device));
+    CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    // every field = haloSize + dimx*dimy*dimz + haloSize elements, data at +haloSize
+    // (TimeLayer3D.h:354, GPUplan.h:79-108), zero-initialised
+    const size_t fbytes = (size_t)(c->ncell + 2 * c->plane) * c->esize;
+    for (int l = 0; l < 5; l++)
+        for (int v = 0; v < 4; v++) { CK(hipMalloc(&c->lay[l][v], fbytes)); CK(hipMemsetAsync(c->lay[l][v], 0, fbytes, c->stream)); }
+    CK(hipMalloc((void **)&c->code, (size_t)c->ncell * sizeof(uint16_t)));
+    for (int v = 0; v < 4; v++) CK(hipMalloc(&c->node[v], (size_t)c->ncell * c->esize));
+    c->red_blocks = 1024;
+    CK(hipMalloc((void **)&c->red_buf, sizeof(double) * 2 * (c->red_blocks + 1)));
+    CK(hipHostMalloc((void **)&c->red_host, sizeof(double) * 2, hipHostMallocDefault));
+    CK(hipStreamSynchronize(c->stream));
+#undef CK
+    *out = c;
+    return FS3D_OK;
+}
+
+extern "C" void fs3d_destroy(fs3d_ctx *c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    fs3d_comm_destroy(c);
+    for (int l = 0; l < 5; l++) for (int v = 0; v < 4; v++) if (c->lay[l][v]) hipFree(c->lay[l][v]);
+    if (c->code) hipFree(c->code);
+    for (int v = 0; v < 4; v++) { if (c->node[v]) hipFree(c->node[v]); if (c->bnd_val[v]) hipFree(c->bnd_val[v]); }
+    for (int v = 0; v < 6; v++) if (c->scr[v]) hipFree(c->scr[v]);
+    if (c->bnd_idx) hipFree(c->bnd_idx);
+    if (c->red_buf) hipFree(c->red_buf);
+    if (c->red_host) hipHostFree(c->red_host);
+    for (auto e : c->ev) hipEventDestroy(e);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" fs3d_status fs3d_set_params(fs3d_ctx *c, double v_T, double v_vis, double t_vis, double t_phi)
+{
+    if (!c) return FS3D_ERR_INVALID;
+    c->v_T = v_T; c->v_vis = v_vis; c->t_vis = t_vis; c->t_phi = t_phi; c->have_params = true;
+    return FS3D_OK;
+}
+
+extern "C" fs3d_status fs3d_set_option(fs3d_ctx *c, int option, int value)
+{
+    if (!c) return FS3D_ERR_INVALID;
+    switch (option) {
+    case FS3D_OPT_SWEEP_KERNEL:
+        if (value < FS3D_SWEEP_AUTO || value > FS3D_SWEEP_PIPE) return fail(c, FS3D_ERR_INVALID, "bad sweep kernel id");
+        c->opt_kernel = value; return FS3D_OK;
+    case FS3D_OPT_FUSE_MERGE: c->opt_fuse = value ? 1 : 0; return FS3D_OK;
+    default: return fail(c, FS3D_ERR_INVALID, "unknown option");
+    }
+}
+
+extern "C" fs3d_status fs3d_enable_timing(fs3d_ctx *c, int on) { if (!c) return FS3D_ERR_INVALID; c->timing = on != 0; return FS3D_OK; }
+
+extern "C" fs3d_status fs3d_last_step_timing(fs3d_ctx *c, float ms[4], int n[4])
+{
+    if (!c) return FS3D_ERR_INVALID;
+    for (int k = 0; k < 4; k++) { if (ms) ms[k] = c->t_ms[k]; if (n) n[k] = c->t_n[k]; }
+    return FS3D_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// geometry: row codes from the node-type array
+// ---------------------------------------------------------------------------------
+
+// Per-line restatement of Grid3D::GenerateListSegments (Grid3D.cpp:47-127, nblockZ = 1):
+// walk the line; a run of NODE_IN cells opened at pos+1 takes the cell at pos as its
+// first node and the first non-IN cell after it as its last node; a run that reaches the
+// end of the line without a closing cell is dropped.  kinds[] gets START/INTERIOR/END.
+// Returns the number of segments; *shared_free is set when a cell closes one segment and
+// opens the next while carrying a FREE boundary condition (two different rows on one cell).
+static int line_kinds(const uint8_t *type, long long base, long long stride, int n, uint8_t *kinds,
+                      const uint8_t *bc_vel, const uint8_t *bc_temp, bool *shared_free)
+{
+    int nseg = 0, state = 0, start = 0;
+    for (int s = 0; s < n; s++) kinds[s] = ROW_SKIP;
+    for (int pos = 0; pos + 1 < n; pos++) {
+        if (type[base + (long long)(pos + 1) * stride] == FS3D_NODE_IN) {
+            if (state == 0) start = pos;
+            state = 1;
+        } else if (state == 1) {
+            const int end = pos + 1;
+            if (kinds[start] == ROW_END) {   // closes the previous segment and opens this one
+                const long long id = base + (long long)start * stride;
+                if (bc_vel[id] == FS3D_BC_FREE || bc_temp[id] == FS3D_BC_FREE) *shared_free = true;
+            }
+            kinds[start] = ROW_START;
+            for (int s = start + 1; s < end; s++) kinds[s] = ROW_INTERIOR;
+            kinds[end] = ROW_END;
+            nseg++;
+            state = 0;
+        }
+    }
+    return nseg;
+}
+
+template <typename R>
+static fs3d_status upload_nodes_impl(fs3d_ctx *c, const uint8_t *type, const uint8_t *bc_vel, const uint8_t *bc_temp,
+                                     const R *vx, const R *vy, const R *vz, const R *T, int n_seg_out[3])
+{
+    const int gx = c->dimx_global, dy = c->dimy, dz = c->dimz, x0 = c->x_offset, nx = c->dimx;
+    const long long plane = c->plane;
+    std::vector<uint16_t> code((size_t)c->ncell, 0);
+    std::vector<uint8_t> kinds((size_t)std::max(gx, std::max(dy, dz)));
+    bool shared_free = false;
+    long long nseg[3] = {0, 0, 0};
+    auto put = [&](int dir, long long gid, int kind) {
+        const int gi = (int)(gid / plane);
+        if (gi < x0 || gi >= x0 + nx) return;
+        int rc = kind;
+        if (kind == ROW_START || kind == ROW_END) {
+            if (bc_vel[gid] == FS3D_BC_FREE) rc |= ROW_VELFREE;
+            if (bc_temp[gid] == FS3D_BC_FREE) rc |= ROW_TEMPFREE;
+        }
+        code[(size_t)(gid - (long long)x0 * plane)] |= (uint16_t)(rc << (4 * dir));
+    };
+    // X lines span all slabs: kinds come from the global line (as the reference builds
+    // global segments and clips them per device, AdiSolver3D.cpp:475-524)
+    for (int j = 0; j < dy; j++)
+        for (int k = 0; k < dz; k++) {
+            const long long base = (long long)j * dz + k;
+            nseg[0] += line_kinds(type, base, plane, gx, kinds.data(), bc_vel, bc_temp, &shared_free);
+            for (int s = x0; s < x0 + nx; s++) put(0, base + (long long)s * plane, kinds[s]);
+        }
+    for (int i = x0; i < x0 + nx; i++)
+        for (int k = 0; k < dz; k++) {
+            const long long base = (long long)i * plane + k;
+            nseg[1] += line_kinds(type, base, dz, dy, kinds.data(), bc_vel, bc_temp, &shared_free);
+            for (int s = 0; s < dy; s++) put(1, base + (long long)s * dz, kinds[s]);
+        }
+    for (int i = x0; i < x0 + nx; i++)
+        for (int j = 0; j < dy; j++) {
+            const long long base = (long long)i * plane + (long long)j * dz;
+            nseg[2] += line_kinds(type, base, 1, dz, kinds.data(), bc_vel, bc_temp, &shared_free);
+            for (int s = 0; s < dz; s++) put(2, base + s, kinds[s]);
+        }
+    if (shared_free)
+        return fail(c, FS3D_ERR_UNSUPPORTED,
+                    "fs3d_upload_nodes: a cell with a FREE boundary condition closes one segment and opens the next "
+                    "on the same line (two rows on one cell; the reference's result there depends on thread timing)");
+    std::vector<int> bidx;
+    std::vector<R> bval[4];
+    std::vector<R> nv[4];
+    for (int v = 0; v < 4; v++) nv[v].resize((size_t)c->ncell);
+    for (long long l = 0; l < c->ncell; l++) {
+        const long long g = l + (long long)x0 * plane;
+        code[(size_t)l] |= (uint16_t)((type[g] & 3) << CODE_TYPE_SHIFT);
+        nv[0][l] = vx[g]; nv[1][l] = vy[g]; nv[2][l] = vz[g]; nv[3][l] = T[g];
+        if (type[g] == FS3D_NODE_BOUND || type[g] == FS3D_NODE_VALVE) {
+            bidx.push_back((int)l);
+            bval[0].push_back(vx[g]); bval[1].push_back(vy[g]); bval[2].push_back(vz[g]); bval[3].push_back(T[g]);
+        }
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpy(c->code, code.data(), code.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    for (int v = 0; v < 4; v++)
+        HIPCHK(c, hipMemcpy(c->node[v], nv[v].data(), (size_t)c->ncell * sizeof(R), hipMemcpyHostToDevice));
+    if (c->bnd_idx) { hipFree(c->bnd_idx); c->bnd_idx = nullptr; }
+    for (int v = 0; v < 4; v++) if (c->bnd_val[v]) { hipFree(c->bnd_val[v]); c->bnd_val[v] = nullptr; }
+    c->n_bnd = (int)bidx.size();
+    if (c->n_bnd) {
+        HIPCHK(c, hipMalloc((void **)&c->bnd_idx, sizeof(int) * bidx.size()));
+        HIPCHK(c, hipMemcpy(c->bnd_idx, bidx.data(), sizeof(int) * bidx.size(), hipMemcpyHostToDevice));
+        for (int v = 0; v < 4; v++) {
+            HIPCHK(c, hipMalloc(&c->bnd_val[v], sizeof(R) * bidx.size()));
+            HIPCHK(c, hipMemcpy(c->bnd_val[v], bval[v].data(), sizeof(R) * bidx.size(), hipMemcpyHostToDevice));
+        }
+    }
+    for (int d = 0; d < 3; d++) { c->nseg[d] = (int)nseg[d]; if (n_seg_out) n_seg_out[d] = (int)nseg[d]; }
+    c->have_nodes = true;
+    return FS3D_OK;
+}
+
+extern "C" fs3d_status fs3d_upload_nodes(fs3d_ctx *c, const uint8_t *type, const uint8_t *bc_vel, const uint8_t *bc_temp,
+                                         const void *vx, const void *vy, const void *vz, const void *T, int n_seg_out[3])
+{
+    if (!c) return FS3D_ERR_INVALID;
+    if (!type || !bc_vel || !bc_temp || !vx || !vy || !vz || !T) return fail(c, FS3D_ERR_INVALID, "fs3d_upload_nodes: NULL array");
+    if (c->prec == FS3D_F32)
+        return upload_nodes_impl<float>(c, type, bc_vel, bc_temp, (const float *)vx, (const float *)vy, (const float *)vz, (const float *)T, n_seg_out);
+    return upload_nodes_impl<double>(c, type, bc_vel, bc_temp, (const double *)vx, (const double *)vy, (const double *)vz, (const double *)T, n_seg_out);
+}
+
+// ---------------------------------------------------------------------------------
+// layers
+// ---------------------------------------------------------------------------------
+
+static fs3d_status check_layer(fs3d_ctx *c, int layer)
+{
+    if (layer < 0 || layer > 3) return fail(c, FS3D_ERR_INVALID, "bad layer id");
+    return FS3D_OK;
+}
+
+extern "C" fs3d_status fs3d_init_layers_from_nodes(fs3d_ctx *c)
+{
+    if (!c) return FS3D_ERR_INVALID;
+    if (!c->have_nodes) return fail(c, FS3D_ERR_INVALID, "fs3d_init_layers_from_nodes: upload nodes first");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t fbytes = (size_t)(c->ncell + 2 * c->plane) * c->esize;
+    for (int l = 0; l < 5; l++) for (int v = 0; v < 4; v++) HIPCHK(c, hipMemsetAsync(c->lay[l][v], 0, fbytes, c->stream));
+    for (int l = 0; l < 4; l++) c->slot[l] = l;
+    c->spare = 4;
+    for (int v = 0; v < 4; v++)
+        HIPCHK(c, hipMemcpyAsync((char *)c->lay[c->slot[FS3D_LAYER_CUR]][v] + c->plane * c->esize, c->node[v],
+                                 (size_t)c->ncell * c->esize, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return FS3D_OK;
+}
+
+extern "C" fs3d_status fs3d_upload_layer(fs3d_ctx *c, int layer, const void *u, const void *v, const void *w, const void *T)
+{
+    if (!c) return FS3D_ERR_INVALID;
+    if (check_layer(c, layer)) return FS3D_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    const void *src[4] = {u, v, w, T};
+    for (int k = 0; k < 4; k++)
+        if (src[k])
+            HIPCHK(c, hipMemcpyAsync((char *)c->lay[c->slot[layer]][k] + c->plane * c->esize, src[k],
+                                     (size_t)c->ncell * c->esize, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return FS3D_OK;
+}
+
+extern "C" fs3d_status fs3d_download_layer(fs3d_ctx *c, int layer, void *u, void *v, void *w, void *T)
+{
+    if (!c) return FS3D_ERR_INVALID;
+    if (check_layer(c, layer)) return FS3D_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    void *dst[4] = {u, v, w, T};
+    for (int k = 0; k < 4; k++)
+        if (dst[k])
+            HIPCHK(c, hipMemcpyAsync(dst[k], (char *)c->lay[c->slot[layer]][k] + c->plane * c->esize,
+                                     (size_t)c->ncell * c->esize, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return FS3D_OK;
+}
+
+extern "C" fs3d_status fs3d_field_dev_ptr(fs3d_ctx *c, int layer, int var, void **dev_ptr)
+{
+    if (!c || !dev_ptr) return FS3D_ERR_INVALID;
+    if (check_layer(c, layer) || var < 0 || var > 3) return fail(c, FS3D_ERR_INVALID, "bad layer/var id");
+    *dev_ptr = (char *)c->lay[c->slot[layer]][var] + c->plane * c->esize;
+    return FS3D_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// hot path
+// ---------------------------------------------------------------------------------
+
+template <typename R>
+static void fill_params(fs3d_ctx *c, SweepParams<R> &p, int dir, double dt_, int b_cur, int b_temp, int b_next, int b_tout, int merge)
+{
+    p.dimx = c->dimx; p.dimy = c->dimy; p.dimz = c->dimz; p.plane = c->plane;
+    for (int v = 0; v < 4; v++) {
+        p.cur[v] = fld<R>(c, b_cur, v); p.temp[v] = fld<R>(c, b_temp, v);
+        p.next[v] = fld<R>(c, b_next, v); p.temp_out[v] = fld<R>(c, b_tout, v);
+        p.node[v] = (const R *)c->node[v];
+    }
+    for (int v = 0; v < 6; v++) p.scr[v] = (R *)c->scr[v];
+    p.code = c->code;
+    // every constant below is evaluated in FTYPE exactly as the reference writes it
+    const R dx = (R)c->gdx, dy = (R)c->gdy, dz = (R)c->gdz;          // TimeLayer3D.h:1078-1080
+    const R ds = dir == 0 ? dx : (dir == 1 ? dy : dz);
+    const R dt = (R)dt_;                                             // FluidSolver3D.cpp:242 (FTYPE)dt
+    const R v_vis = (R)c->v_vis, t_vis = (R)c->t_vis;
+    p.two_ds[0] = 2 * dx; p.two_ds[1] = 2 * dy; p.two_ds[2] = 2 * dz;   // TimeLayer3D.h:338-340
+    p.vis_v = v_vis / (ds * ds);                                     // AdiSolver3D.cpp:744-746
+    p.vis_t = t_vis / (ds * ds);                                     // AdiSolver3D.cpp:749-751
+    p.b_v = 3 / dt + 2 * p.vis_v;                                    // AdiSolver3D.cpp:761
+    p.b_t = 3 / dt + 2 * p.vis_t;
+    p.dt = dt; p.v_T = (R)c->v_T; p.t_phi = (R)c->t_phi;
+    p.merge = merge;
+}
+
+static fs3d_status ensure_scratch(fs3d_ctx *c)
+{
+    if (c->scr[0]) return FS3D_OK;
+    for (int v = 0; v < 6; v++) HIPCHK(c, hipMalloc(&c->scr[v], (size_t)c->ncell * c->esize));
+    return FS3D_OK;
+}
+
+// one sweep on explicit buffers; merge: 0 none, 1 fused merge, 2 fused merge twice
+template <typename R>
+static fs3d_status sweep_buffers(fs3d_ctx *c, int dir, double dt, int b_cur, int b_temp, int b_next, int b_tout, int merge)
+{
+    SweepParams<R> p;
+    fill_params<R>(c, p, dir, dt, b_cur, b_temp, b_next, b_tout, merge);
+    rec_begin(c, dir == 2 ? 0 : (dir == 1 ? 1 : 2));
+    bool done = false;
+    if (c->opt_kernel != FS3D_SWEEP_LINE) done = launch_sweep_pipe<R>(c, dir, p);
+    if (!done) {
+        if (c->opt_kernel == FS3D_SWEEP_PIPE) { rec_end(c); return fail(c, FS3D_ERR_UNSUPPORTED, "pipelined sweep kernel does not support these dims"); }
+        fs3d_status st = ensure_scratch(c);
+        if (st) return st;
+        fill_params<R>(c, p, dir, dt, b_cur, b_temp, b_next, b_tout, merge);
+        launch_sweep_line<R>(c, dir, p);
+    }
+    rec_end(c);
+    HIPCHK(c, hipGetLastError());
+    return FS3D_OK;
+}
+
+template <typename R>
+static fs3d_status merge_buffers(fs3d_ctx *c, int b_src, int b_dest)
+{
+    rec_begin(c, 3);
+    hipLaunchKernelGGL((k_merge<R>), dim3(grid_for(c->ncell, 256)), dim3(256), 0, c->stream, c->code, c->ncell,
+                       fld<R>(c, b_src, 0), fld<R>(c, b_src, 1), fld<R>(c, b_src, 2), fld<R>(c, b_src, 3),
+                       fld<R>(c, b_dest, 0), fld<R>(c, b_dest, 1), fld<R>(c, b_dest, 2), fld<R>(c, b_dest, 3));
+    rec_end(c);
+    HIPCHK(c, hipGetLastError());
+    return FS3D_OK;
+}
+
+template <typename R>
+static fs3d_status update_boundaries_impl(fs3d_ctx *c)
+{
+    if (!c->n_bnd) return FS3D_OK;
+    const int b = c->slot[FS3D_LAYER_CUR];
+    rec_begin(c, 3);
+    hipLaunchKernelGGL((k_impose_list<R>), dim3((c->n_bnd + 255) / 256), dim3(256), 0, c->stream, c->bnd_idx, c->n_bnd,
+                       (const R *)c->bnd_val[0], (const R *)c->bnd_val[1], (const R *)c->bnd_val[2], (const R *)c->bnd_val[3],
+                       fld<R>(c, b, 0), fld<R>(c, b, 1), fld<R>(c, b, 2), fld<R>(c, b, 3));
+    rec_end(c);
+    HIPCHK(c, hipGetLastError());
+    return FS3D_OK;
+}
+
+extern "C" fs3d_status fs3d_update_boundaries(fs3d_ctx *c)
+{
+    if (!c) return FS3D_ERR_INVALID;
+    if (!c->have_nodes) return fail(c, FS3D_ERR_INVALID, "fs3d_update_boundaries: upload nodes first");
+    HIPCHK(c, hipSetDevice(c->device));
+    fs3d_status st = c->prec == FS3D_F32 ? update_boundaries_impl<float>(c) : update_boundaries_impl<double>(c);
+    if (st) return st;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return FS3D_OK;
+}
+
+template <typename R>
+static fs3d_status div_error_enqueue(fs3d_ctx *c, int layer)
+{
+    const int b = c->slot[layer];
+    // the last slab skips its final plane (TimeLayer3D.h:606); inner slabs need the i-1 ghost (halo exchanged by caller)
+    const int i_end = (c->x_offset + c->dimx == c->dimx_global) ? c->dimx - 1 : c->dimx;
+    rec_begin(c, 3);
+    hipLaunchKernelGGL((k_div_error<R>), dim3(c->red_blocks), dim3(256), 0, c->stream, c->code,
+                       (const R *)fld<R>(c, b, 0), (const R *)fld<R>(c, b, 1), (const R *)fld<R>(c, b, 2),
+                       c->dimx, c->dimy, c->dimz, i_end, (R)c->gdx, (R)c->gdy, (R)c->gdz, c->red_buf + 2);
+    hipLaunchKernelGGL(k_div_final, dim3(1), dim3(256), 0, c->stream, c->red_buf + 2, c->red_blocks, c->red_buf);
+    rec_end(c);
+    HIPCHK(c, hipGetLastError());
+    return FS3D_OK;
+}
+
+static fs3d_status div_error_finish(fs3d_ctx *c, double *err, long long *count)
+{
+    fs3d_status st = fs3d_comm_allreduce_sum2(c, c->red_buf);   // no-op for a single rank
+    if (st) return st;
+    HIPCHK(c, hipMemcpyAsync(c->red_host, c->red_buf, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (count) *count = (long long)c->red_host[1];
+    if (err) *err = c->red_host[0] / c->red_host[1];   // err / count (0/0 = NaN as in the reference)
+    return FS3D_OK;
+}
+
+extern "C" fs3d_status fs3d_eval_div_error(fs3d_ctx *c, int layer, double *err_out, long long *count_out)
+{
+    if (!c) return FS3D_ERR_INVALID;
+    if (check_layer(c, layer)) return FS3D_ERR_INVALID;
+    if (!c->have_nodes) return fail(c, FS3D_ERR_INVALID, "fs3d_eval_div_error: upload nodes first");
+    HIPCHK(c, hipSetDevice(c->device));
+    fs3d_status st = fs3d_comm_halo_exchange(c, c->slot[layer], 3);   // U,V,W ghosts (TimeLayer3D.h:601-603)
+    if (st) return st;
+    st = c->prec == FS3D_F32 ? div_error_enqueue<float>(c, layer) : div_error_enqueue<double>(c, layer);
+    if (st) return st;
+    return div_error_finish(c, err_out, count_out);
+}
+
+extern "C" fs3d_status fs3d_sweep(fs3d_ctx *c, int dir, double dt, int l_cur, int l_temp, int l_next, int merge_into_temp)
+{
+    if (!c) return FS3D_ERR_INVALID;
+    if (dir < 0 || dir > 2 || check_layer(c, l_cur) || check_layer(c, l_temp) || check_layer(c, l_next))
+        return fail(c, FS3D_ERR_INVALID, "fs3d_sweep: bad direction or layer id");
+    if (!c->have_nodes || !c->have_params) return fail(c, FS3D_ERR_INVALID, "fs3d_sweep: upload nodes and set params first");
+    if (l_next == l_cur || l_next == l_temp) return fail(c, FS3D_ERR_INVALID, "fs3d_sweep: next must differ from cur and temp");
+    HIPCHK(c, hipSetDevice(c->device));
+    fs3d_status st = fs3d_comm_halo_exchange(c, c->slot[l_temp], 4);   // temp->syncHalos (AdiSolver3D.cpp:608)
+    if (st) return st;
+    const bool f32 = c->prec == FS3D_F32;
+    if (merge_into_temp && c->opt_fuse) {
+        const int bt = c->slot[l_temp], bo = c->spare;
+        st = f32 ? sweep_buffers<float>(c, dir, dt, c->slot[l_cur], bt, c->slot[l_next], bo, 1)
+                 : sweep_buffers<double>(c, dir, dt, c->slot[l_cur], bt, c->slot[l_next], bo, 1);
+        if (st) return st;
+        c->slot[l_temp] = bo; c->spare = bt;
+    } else {
+        const int bt = c->slot[l_temp];
+        st = f32 ? sweep_buffers<float>(c, dir, dt, c->slot[l_cur], bt, c->slot[l_next], bt, 0)
+                 : sweep_buffers<double>(c, dir, dt, c->slot[l_cur], bt, c->slot[l_next], bt, 0);
+        if (st) return st;
+        if (merge_into_temp) {
+            st = f32 ? merge_buffers<float>(c, c->slot[l_next], bt) : merge_buffers<double>(c, c->slot[l_next], bt);
+            if (st) return st;
+        }
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->timing) rec_collect(c);
+    return FS3D_OK;
+}
+
+extern "C" fs3d_status fs3d_merge(fs3d_ctx *c, int l_src, int l_dest)
+{
+    if (!c) return FS3D_ERR_INVALID;
+    if (check_layer(c, l_src) || check_layer(c, l_dest) || l_src == l_dest) return fail(c, FS3D_ERR_INVALID, "fs3d_merge: bad layers");
+    if (!c->have_nodes) return fail(c, FS3D_ERR_INVALID, "fs3d_merge: upload nodes first");
+    HIPCHK(c, hipSetDevice(c->device));
+    fs3d_status st = c->prec == FS3D_F32 ? merge_buffers<float>(c, c->slot[l_src], c->slot[l_dest])
+                                         : merge_buffers<double>(c, c->slot[l_src], c->slot[l_dest]);
+    if (st) return st;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return FS3D_OK;
+}
+
+// AdiSolver3D::TimeStep, AdiSolver3D.cpp:306-391, enqueued on the context's stream.
+template <typename R>
+static fs3d_status time_step_enqueue(fs3d_ctx *c, double dt, int G, int L, bool compute_error)
+{
+    const int bCur = c->slot[FS3D_LAYER_CUR], bNext = c->slot[FS3D_LAYER_NEXT], bHalf = c->slot[FS3D_LAYER_HALF];
+    fs3d_status st;
+    // :310-311  cur -> next on NODE_BOUND and NODE_VALVE
+    if (c->n_bnd) {
+        rec_begin(c, 3);
+        hipLaunchKernelGGL((k_copy_list<R>), dim3((c->n_bnd + 255) / 256), dim3(256), 0, c->stream, c->bnd_idx, c->n_bnd,
+                           (const R *)fld<R>(c, bCur, 0), (const R *)fld<R>(c, bCur, 1), (const R *)fld<R>(c, bCur, 2), (const R *)fld<R>(c, bCur, 3),
+                           fld<R>(c, bNext, 0), fld<R>(c, bNext, 1), fld<R>(c, bNext, 2), fld<R>(c, bNext, 3));
+        rec_end(c);
+    }
+    const bool fuse = c->opt_fuse && L >= 1 && G >= 1;
+    if (!fuse) {
+        // :320 cur->CopyLayerTo(temp)
+        rec_begin(c, 3);
+        for (int v = 0; v < 4; v++)
+            HIPCHK(c, hipMemcpyAsync(fld<R>(c, c->slot[FS3D_LAYER_TEMP], v), fld<R>(c, bCur, v), (size_t)c->ncell * sizeof(R),
+                                     hipMemcpyDeviceToDevice, c->stream));
+        rec_end(c);
+        for (int it = 0; it < G; it++) {
+            const int bT = c->slot[FS3D_LAYER_TEMP];
+            const int plan[3][3] = {{2, bCur, bNext}, {1, bNext, bHalf}, {0, bHalf, bNext}};   // :338, :342, :343
+            for (int d = 0; d < 3; d++)
+                for (int l = 0; l < L; l++) {
+                    if ((st = fs3d_comm_halo_exchange(c, bT, 4))) return st;
+                    if ((st = sweep_buffers<R>(c, plan[d][0], dt, plan[d][1], bT, plan[d][2], bT, 0))) return st;
+                    if ((st = merge_buffers<R>(c, plan[d][2], bT))) return st;                 // :651
+                }
+            if ((st = merge_buffers<R>(c, bNext, bT))) return st;                               // :354
+        }
+    } else {
+        // Fused form.  The sweep kernel writes next and the merged temp in one pass
+        // (temp is double-buffered so cross-line stencil reads still see the un-merged temp);
+        // the first sweep reads temp straight from cur (saves the :320 copy); the last X
+        // sweep of each global iteration applies the :354 merge as a second averaging step.
+        int bTin = bCur;                       // temp == cur until the first merge
+        int bTout = c->slot[FS3D_LAYER_TEMP];
+        int bSpare = c->spare;
+        for (int it = 0; it < G; it++) {
+            const int plan[3][3] = {{2, bCur, bNext}, {1, bNext, bHalf}, {0, bHalf, bNext}};
+            for (int d = 0; d < 3; d++)
+                for (int l = 0; l < L; l++) {
+                    const int merge = (d == 2 && l == L - 1) ? 2 : 1;
+                    if ((st = fs3d_comm_halo_exchange(c, bTin, 4))) return st;
+                    if ((st = sweep_buffers<R>(c, plan[d][0], dt, plan[d][1], bTin, plan[d][2], bTout, merge))) return st;
+                    if (bTin == bCur) { bTin = bTout; bTout = bSpare; }
+                    else { int t = bTin; bTin = bTout; bTout = t; }
+                }
+        }
+        c->slot[FS3D_LAYER_TEMP] = bTin; c->spare = bTout;
+    }
+    if (compute_error) {
+        if ((st = fs3d_comm_halo_exchange(c, bNext, 3))) return st;
+        if ((st = div_error_enqueue<R>(c, FS3D_LAYER_NEXT))) return st;
+    }
+    return FS3D_OK;
+}
+
+extern "C" fs3d_status fs3d_time_step(fs3d_ctx *c, double dt, int G, int L, int compute_error, double *err_out)
+{
+    if (!c) return FS3D_ERR_INVALID;
+    if (!c->have_nodes || !c->have_params) return fail(c, FS3D_ERR_INVALID, "fs3d_time_step: upload nodes and set params first");
+    if (G < 0 || L < 0 || !(dt > 0)) return fail(c, FS3D_ERR_INVALID, "fs3d_time_step: bad dt / iteration counts");
+    HIPCHK(c, hipSetDevice(c->device));
+    fs3d_status st = c->prec == FS3D_F32 ? time_step_enqueue<float>(c, dt, G, L, compute_error != 0)
+                                         : time_step_enqueue<double>(c, dt, G, L, compute_error != 0);
+    if (st) return st;
+    if (compute_error) {
+        double e = 0;
+        if ((st = div_error_finish(c, &e, nullptr))) return st;
+        c->diffError = e;                                                    // :366
+    } else {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    if (c->timing) rec_collect(c);
+    if (err_out) *err_out = c->diffError;
+    if (c->diffError > 0.01) {                                               // :371-374 (ERR_THRESHOLD, AdiSolver3D.h:32)
+        char b[128]; snprintf(b, sizeof b, "Error is too big! %f", c->diffError);
+        return fail(c, FS3D_ERR_DIVERGED, b);
+    }
+    std::swap(c->slot[FS3D_LAYER_CUR], c->slot[FS3D_LAYER_NEXT]);            // :388-390
+    return FS3D_OK;
+}
+
+extern "C" fs3d_status fs3d_time_step_async(fs3d_ctx *c, double dt, int G, int L)
+{
+    if (!c) return FS3D_ERR_INVALID;
+    if (!c->have_nodes || !c->have_params) return fail(c, FS3D_ERR_INVALID, "fs3d_time_step_async: upload nodes and set params first");
+    if (G < 0 || L < 0 || !(dt > 0)) return fail(c, FS3D_ERR_INVALID, "fs3d_time_step_async: bad dt / iteration counts");
+    HIPCHK(c, hipSetDevice(c->device));
+    fs3d_status st = c->prec == FS3D_F32 ? update_boundaries_impl<float>(c) : update_boundaries_impl<double>(c);
+    if (st) return st;
+    st = c->prec == FS3D_F32 ? time_step_enqueue<float>(c, dt, G, L, false) : time_step_enqueue<double>(c, dt, G, L, false);
+    if (st) return st;
+    std::swap(c->slot[FS3D_LAYER_CUR], c->slot[FS3D_LAYER_NEXT]);
+    return FS3D_OK;
+}
+
+extern "C" fs3d_status fs3d_synchronize(fs3d_ctx *c)
+{
+    if (!c) return FS3D_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->timing) rec_collect(c);
+    return FS3D_OK;
+}
+
+// Solver3D::GetLayer, Solver3D.cpp:21-25
+template <typename R>
+static fs3d_status get_layer_impl(fs3d_ctx *c, R *outV, double *outT, int odx, int ody, int odz)
+{
+    const int b = c->slot[FS3D_LAYER_NEXT];
+    hipLaunchKernelGGL((k_clear_type<R>), dim3(grid_for(c->ncell, 256)), dim3(256), 0, c->stream, c->code, c->ncell,
+                       (int)FS3D_NODE_OUT, (R)99999.0f, fld<R>(c, b, 0), fld<R>(c, b, 1), fld<R>(c, b, 2), fld<R>(c, b, 3));
+    HIPCHK(c, hipGetLastError());
+    std::vector<R> h[4];
+    for (int v = 0; v < 4; v++) {
+        h[v].resize((size_t)c->ncell);
+        HIPCHK(c, hipMemcpyAsync(h[v].data(), fld<R>(c, b, v), (size_t)c->ncell * sizeof(R), hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (odx == 0) odx = c->dimx;
+    if (ody == 0) ody = c->dimy;
+    if (odz == 0) odz = c->dimz;
+    // FilterToArrays, TimeLayer3D.h:819-924 (single slab; a multi-GPU caller gathers the slabs)
+    for (int i = 0; i < odx; i++)
+        for (int j = 0; j < ody; j++)
+            for (int k = 0; k < odz; k++) {
+                const int x = i * c->dimx / odx, y = j * c->dimy / ody, z = k * c->dimz / odz;
+                const size_t ind = (size_t)i * ody * odz + (size_t)j * odz + k;
+                const size_t id = (size_t)x * c->plane + (size_t)y * c->dimz + z;
+                outV[3 * ind] = h[0][id]; outV[3 * ind + 1] = h[1][id]; outV[3 * ind + 2] = h[2][id];
+                outT[ind] = h[3][id];
+            }
+    return FS3D_OK;
+}
+
+extern "C" fs3d_status fs3d_get_layer(fs3d_ctx *c, void *outV, double *outT, int odx, int ody, int odz)
+{
+    if (!c || !outV || !outT) return FS3D_ERR_INVALID;
+    if (!c->have_nodes) return fail(c, FS3D_ERR_INVALID, "fs3d_get_layer: upload nodes first");
+    if (odx < 0 || ody < 0 || odz < 0) return fail(c, FS3D_ERR_INVALID, "fs3d_get_layer: negative output dims");
+    HIPCHK(c, hipSetDevice(c->device));
+    return c->prec == FS3D_F32 ? get_layer_impl<float>(c, (float *)outV, outT, odx, ody, odz)
+                               : get_layer_impl<double>(c, (double *)outV, outT, odx, ody, odz);
+}

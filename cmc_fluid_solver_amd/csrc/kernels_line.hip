@@ -1,0 +1,87 @@
+// Thread-per-line Thomas sweep (FS3D_SWEEP_LINE): the fully general kernel.
+//
+// One thread owns one grid line of the sweep direction and runs the reference's
+// sequential recurrence (Algorithms.h:21-38) over it: forward elimination writes
+// c'(2) and d'(4) per cell to an HBM scratch, back-substitution reads them in reverse
+// and scatters x into `next` (UpdateSegment, AdiSolver3D.cpp:707-730), optionally
+// followed by the merge into temp (MergeLayerTo, TimeLayer3D.h:664-683).
+// X and Y sweeps are coalesced (lanes along k); the Z sweep is not (lanes along j) --
+// this kernel is the correctness baseline and the fallback for dims the pipelined
+// kernel does not cover.  HBM traffic: 8 (in) + 6 (scratch out) + 6 (scratch in)
+// + 4 (temp again) + 8 (out) = 32 words/cell against the 16-word algorithmic figure.
+#include "fs3d_rows.h"
+
+template <typename R, int DIR>
+__global__ void __launch_bounds__(256) k_sweep_line(SweepParams<R> p)
+{
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long nlines, base, stride;
+    int n;
+    if (DIR == 0) { nlines = p.plane; base = tid; stride = p.plane; n = p.dimx; }
+    else if (DIR == 1) {
+        nlines = (long long)p.dimx * p.dimz;
+        base = (tid / p.dimz) * p.plane + (tid % p.dimz); stride = p.dimz; n = p.dimy;
+    } else { nlines = (long long)p.dimx * p.dimy; base = tid * p.dimz; stride = 1; n = p.dimz; }
+    if (tid >= nlines) return;
+
+    R cp_v = R(0), cp_t = R(0), dp[4] = {R(0), R(0), R(0), R(0)};
+    for (int s = 0; s < n; s++) {
+        const long long idx = base + s * stride;
+        const int code = (p.code[idx] >> (4 * DIR)) & 0xF;
+        const int kind = code & 3;
+        RowUVWT<R> r;
+        if (kind == ROW_INTERIOR) build_interior_row<R, DIR>(p, idx, r);
+        else if (kind != ROW_SKIP) build_bc_row<R>(p, idx, code, r);
+        thomas_forward<R>(kind, r, cp_v, cp_t, dp);
+        p.scr[0][idx] = cp_v; p.scr[1][idx] = cp_t;
+        p.scr[2][idx] = dp[0]; p.scr[3][idx] = dp[1]; p.scr[4][idx] = dp[2]; p.scr[5][idx] = dp[3];
+    }
+    // back-substitution: x[n-1] = d'[n-1]; x[i] = d'[i] - c'[i]*x[i+1]
+    R x[4] = {R(0), R(0), R(0), R(0)};
+    for (int s = n - 1; s >= 0; s--) {
+        const long long idx = base + s * stride;
+        const int cw = p.code[idx];
+        const int kind = (cw >> (4 * DIR)) & 3;
+        const R c_v = p.scr[0][idx], c_t = p.scr[1][idx];
+        const R d0 = p.scr[2][idx], d1 = p.scr[3][idx], d2 = p.scr[4][idx], d3 = p.scr[5][idx];
+        if (kind == ROW_END || kind == ROW_SKIP) { x[0] = d0; x[1] = d1; x[2] = d2; x[3] = d3; }
+        else {
+            x[0] = d0 - c_v * x[0]; x[1] = d1 - c_v * x[1];
+            x[2] = d2 - c_v * x[2]; x[3] = d3 - c_t * x[3];
+        }
+        if (kind != ROW_SKIP) {
+            p.next[0][idx] = x[0]; p.next[1][idx] = x[1]; p.next[2][idx] = x[2]; p.next[3][idx] = x[3];
+        }
+        if (p.merge) {
+            const bool is_in = ((cw >> CODE_TYPE_SHIFT) & 3) == FS3D_NODE_IN;
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                R t = p.temp[v][idx];
+                if (is_in) {
+                    // NODE_IN cell outside every segment (run without a closing cell,
+                    // Grid3D.cpp:87-117): the reference merges the stale `next` value
+                    const R xv = kind != ROW_SKIP ? x[v] : p.next[v][idx];
+                    t = (t + xv) / R(2);
+                    if (p.merge == 2) t = (t + xv) / R(2);
+                }
+                p.temp_out[v][idx] = t;
+            }
+        }
+    }
+}
+
+template <typename R>
+void launch_sweep_line(fs3d_ctx *c, int dir, const SweepParams<R> &p)
+{
+    long long nlines = dir == 0 ? p.plane : (dir == 1 ? (long long)p.dimx * p.dimz : (long long)p.dimx * p.dimy);
+    const int bs = 64;   // few lines exist (N^2): small blocks spread them over all CUs
+    const unsigned grid = (unsigned)((nlines + bs - 1) / bs);
+    switch (dir) {
+    case 0: hipLaunchKernelGGL((k_sweep_line<R, 0>), dim3(grid), dim3(bs), 0, c->stream, p); break;
+    case 1: hipLaunchKernelGGL((k_sweep_line<R, 1>), dim3(grid), dim3(bs), 0, c->stream, p); break;
+    default: hipLaunchKernelGGL((k_sweep_line<R, 2>), dim3(grid), dim3(bs), 0, c->stream, p); break;
+    }
+}
+
+template void launch_sweep_line<float>(fs3d_ctx *, int, const SweepParams<float> &);
+template void launch_sweep_line<double>(fs3d_ctx *, int, const SweepParams<double> &);
