@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""Benchmark of the FluidSolver3D step (BASELINE.json metric): Mcells/s of one
+AdiSolver3D::TimeStep (+ UpdateBoundaries, + EvalDivError every 10th step, exactly the
+reference's time loop, FluidSolver3D.cpp:226-262) on the synthetic 256^3 fp32 box.
+
+  python bench.py --gpus N --steps K --warmup W
+
+N = 1: one context on cuda:0.  N > 1 (launched by torch.distributed.run, one rank per
+GPU): the 256^3 box is cut into N x-slabs (strong scaling); halo planes, the cross-slab
+X solve and the 2-scalar error reduction go over RCCL inside libfs3d_hip.so; torch.distributed
+only carries the ncclUniqueId and the barrier / max-over-ranks timing.
+
+Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events on the
+library's stream over the timed region; `cpu_baseline` times the CPU oracle (a port of
+the reference's CPU path) on a bounded sample of the same workload on this host.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+RE, PR, LAMBDA = 200.0, 0.72, 1.4
+NUM_GLOBAL, NUM_LOCAL = 4, 2   # data/3D/**/*config.txt: num_global 4, num_local 2
+
+
+def cpu_baseline(n, dt, steps):
+    """The CPU oracle (port of the reference's CPU path) on the same workload, bounded sample."""
+    from oracle import oracle as O
+    from cmc_fluid_solver_amd import capi, grids
+    g = grids.box(n, h=1.0 / (n - 1))
+    params = capi.fluid_params(np.float32, RE, PR, LAMBDA)
+    o = O.Oracle(g, params, np.float32)
+    o.update_boundaries(); o.time_step(dt, NUM_GLOBAL, NUM_LOCAL, False)   # warm-up (page faults, OpenMP team)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        o.update_boundaries()
+        o.time_step(dt, NUM_GLOBAL, NUM_LOCAL, i % 10 == 0)
+    sec = time.perf_counter() - t0
+    o.close()
+    return {"value": round(n ** 3 * steps / sec / 1e6, 3), "unit": "Mcells/s", "cores": O.num_threads(),
+            "kind": "port", "sample": "%d steps of the same %d^3 fp32 box (G=%d, L=%d), CPU oracle with OpenMP, "
+            "%.1f s" % (steps, n, NUM_GLOBAL, NUM_LOCAL, sec)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", type=int, default=256, help="box edge (default 256: BASELINE configs[2])")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 line, 2 pipe")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from cmc_fluid_solver_amd import capi, grids
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the HIP path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    n = args.size
+    dtype = np.float32 if args.dtype == "f32" else np.float64
+    h = 1.0 / (n - 1)
+    dt = 0.1                    # every shipped 3D config: duration 10 / time_steps 100 (FluidSolver3D.cpp:196)
+    g = grids.box(n, h=h)
+    params = capi.fluid_params(dtype, RE, PR, LAMBDA)
+    # x-slab of this rank (GPUplan::splitEven1D, GPUplan.cpp:122-141: even split, remainder to the first ranks)
+    q, r = divmod(n, world)
+    x0 = rank * q + min(rank, r)
+    x1 = x0 + q + (1 if rank < r else 0)
+    s = capi.Solver(g, params, dtype, device=local_rank, x_range=(x0, x1))
+    s.set_option(capi.OPT_SWEEP_KERNEL, args.kernel)
+    if world > 1:
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            buf = (capi.C.c_char * 128)()
+            assert capi.load().fs3d_comm_unique_id(buf) == 0
+            uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+        uid = uid.cuda()
+        dist.broadcast(uid, 0)
+        s.comm_init(bytes(uid.cpu().numpy().tobytes()), rank, world)
+
+    def step(i):
+        if i % 10 == 0:      # FluidSolver3D.cpp:242: computeError every 10th step
+            s.UpdateBoundaries()
+            s.TimeStep(dt, NUM_GLOBAL, NUM_LOCAL, True)
+        else:
+            s.time_step_async(dt, NUM_GLOBAL, NUM_LOCAL)   # UpdateBoundaries + TimeStep, enqueued
+
+    def fence():
+        s.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    s.enable_timing(True)      # HIP events around every kernel launch of the timed region
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    fence()
+    sec = time.perf_counter() - t0
+    ms_cls, n_cls = s.last_step_timing()
+    s.enable_timing(False)
+    err, _ = s.eval_div_error(capi.LAYER_CUR)
+    if world > 1:
+        t = torch.tensor([sec], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        sec = float(t.item())
+
+    if rank == 0:
+        cells = n ** 3
+        esize = 4 if dtype == np.float32 else 8
+        # dominant kernel = the sweep class with the largest total device time
+        names = ["sweep_Z", "sweep_Y", "sweep_X"]
+        k = int(np.argmax(ms_cls[:3]))
+        per_launch_ms = ms_cls[k] / max(1, n_cls[k])
+        local_cells = (x1 - x0) * n * n
+        alg_bytes = 16 * esize * local_cells          # 16 words/cell/sweep (cur4+temp4 in, next4+temp4 out)
+        achieved = alg_bytes / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
+        out = {
+            "metric": "Mcells/sec (FluidSolver3D step)", "value": round(cells * args.steps / sec / 1e6, 2),
+            "unit": "Mcells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(sec / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "FluidSolver3D %d^3 %s empty box (shell NODE_BOUND, x=0 inflow valve U=1, x=max free "
+                                   "outflow valve), Re 200 Pr 0.72 lambda 1.4, num_global 4, num_local 2, dt %.5g, "
+                                   "UpdateBoundaries+TimeStep per step, EvalDivError every 10th step" % (n, args.dtype, dt),
+                       "grid": [n, n, n], "parallelism": "x-slab x%d" % world, "sweep_kernel": args.kernel,
+                       "final_div_error": err},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": names[k], "avg_launch_ms": round(per_launch_ms, 4),
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "per_class_ms_per_launch": {nm: round(ms_cls[j] / max(1, n_cls[j]), 4)
+                                                     for j, nm in enumerate(names + ["other"])},
+                         "launches": dict(zip(names + ["other"], n_cls)),
+                         "step_frac_of_hbm_roofline_1760B": round(
+                             (cells * 1760.0 * (esize / 4) * args.steps / sec / 1e9) / (HBM_PEAK_GBS * world), 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(n, dt, args.cpu_steps)
+        print(json.dumps(out))
+    s.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

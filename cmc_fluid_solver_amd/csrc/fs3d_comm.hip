@@ -51,7 +51,7 @@ fs3d_status fs3d_comm_halo_exchange(fs3d_ctx *c, int buf, int nfields)
     // layout per field: [ghost lo][dimx owned planes][ghost hi]; one grouped send/recv per neighbour
     NCCLCHK(c, ncclGroupStart());
     for (int v = 0; v < nfields; v++) {
-        char *base = (char *)c->lay[buf][v];
+        char *base = (char *)c->lay[buf] + (size_t)v * c->fstride * c->esize;
         char *first = base + pl * c->esize;                       // first owned plane
         char *last = base + (size_t)c->dimx * pl * c->esize;      // last owned plane
         char *glo = base;                                         // ghost below

@@ -26,14 +26,23 @@ struct SweepParams {
     // geometry
     int dimx, dimy, dimz;       // owned planes
     long long plane;            // dimy*dimz
-    // layers: 4 fields each, pointers to the first OWNED cell (one halo plane precedes)
-    const R *cur[4];
-    const R *temp[4];           // temp read by the stencils (old temp)
-    R *next[4];
-    R *temp_out[4];             // merged temp (== temp buffers when not double-buffered)
+    // layers: one allocation per layer, field v at + v*fstride; the pointers address the first
+    // OWNED cell of field 0 (one halo plane precedes every field).  Few pointers = few SGPRs.
+    const R *cur_;
+    const R *temp_;             // temp read by the stencils (old temp)
+    R *next_;
+    R *temp_out_;               // merged temp (== temp_ when not double-buffered)
+    long long fstride;          // elements between consecutive fields of a layer
     const uint16_t *code;
-    const R *node[4];           // node boundary values (v.x, v.y, v.z, T)
-    R *scr[6];                  // LINE kernel scratch: c'_uvw, c'_T, d'_U, d'_V, d'_W, d'_T
+    const R *node_;             // node boundary values (v.x, v.y, v.z, T), field v at + v*nstride
+    R *scr_;                    // LINE kernel scratch: c'_uvw, c'_T, d'_U, d'_V, d'_W, d'_T at + v*nstride
+    long long nstride;          // = number of owned cells
+    __host__ __device__ const R *cur(int v) const { return cur_ + v * fstride; }
+    __host__ __device__ const R *temp(int v) const { return temp_ + v * fstride; }
+    __host__ __device__ R *next(int v) const { return next_ + v * fstride; }
+    __host__ __device__ R *temp_out(int v) const { return temp_out_ + v * fstride; }
+    __host__ __device__ const R *node(int v) const { return node_ + v * nstride; }
+    __host__ __device__ R *scr(int v) const { return scr_ + v * nstride; }
     // constants, all rounded exactly as the reference's FTYPE expressions
     R two_ds[3];                // 2*dx, 2*dy, 2*dz            (TimeLayer3D.h:338-340)
     R vis_v, vis_t;             // v_vis/(ds*ds), t_vis/(ds*ds) (AdiSolver3D.cpp:744-751) for the sweep axis
@@ -52,13 +61,14 @@ struct fs3d_ctx {
     bool have_params = false, have_nodes = false;
     size_t esize = 4;
     long long plane = 0, ncell = 0;
-    // 5 layer buffers (cur,temp,half,next + spare temp for double-buffering); [buf][var] = base alloc (with halos)
-    void *lay[5][4] = {};
+    // 5 layer buffers (cur,temp,half,next + spare temp for double-buffering)
+    void *lay[5] = {};          // one allocation per layer buffer: 4 fields of fstride elements
+    long long fstride = 0;      // ncell + 2*plane
     int slot[4] = {0, 1, 2, 3}; // layer id -> buffer
     int spare = 4;
     uint16_t *code = nullptr;
-    void *node[4] = {};
-    void *scr[6] = {};
+    void *node = nullptr;       // 4 x ncell
+    void *scr = nullptr;        // 6 x ncell (LINE kernel only, allocated on demand)
     // compact list of NODE_BOUND / NODE_VALVE cells (AdiSolver3D.cpp:286-311)
     int *bnd_idx = nullptr;
     void *bnd_val[4] = {};
@@ -76,6 +86,7 @@ struct fs3d_ctx {
     // timing
     bool timing = false;
     std::vector<hipEvent_t> ev;
+    size_t ev_used = 0;
     std::vector<int> ev_class;
     float t_ms[4] = {0, 0, 0, 0};
     int t_n[4] = {0, 0, 0, 0};

@@ -140,8 +140,9 @@ __global__ void __launch_bounds__(256) k_div_final(const double *partial, int nb
 // context helpers
 // ---------------------------------------------------------------------------------
 
-template <typename R> static R *fld(fs3d_ctx *c, int buf, int v) { return (R *)c->lay[buf][v] + c->plane; }
-template <typename R> static R *lfld(fs3d_ctx *c, int layer, int v) { return fld<R>(c, c->slot[layer], v); }
+template <typename R> static R *fld(fs3d_ctx *c, int buf, int v) { return (R *)c->lay[buf] + (long long)v * c->fstride + c->plane; }
+// byte pointer to the first owned cell of field v of layer buffer buf
+static char *fptr(fs3d_ctx *c, int buf, int v) { return (char *)c->lay[buf] + ((size_t)v * c->fstride + c->plane) * c->esize; }
 
 static inline unsigned grid_for(long long n, int bs, int cap = 4096)
 {
@@ -149,30 +150,34 @@ static inline unsigned grid_for(long long n, int bs, int cap = 4096)
     return (unsigned)std::max(1LL, std::min<long long>(g, cap));
 }
 
+// per-launch HIP-event timing on the context's stream (events are pooled and reused)
 static void rec_begin(fs3d_ctx *c, int cls)
 {
     if (!c->timing) return;
-    hipEvent_t e0, e1;
-    hipEventCreate(&e0); hipEventCreate(&e1);
-    hipEventRecord(e0, c->stream);
-    c->ev.push_back(e0); c->ev.push_back(e1); c->ev_class.push_back(cls);
+    if (c->ev_used + 2 > c->ev.size()) {
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0); hipEventCreate(&e1);
+        c->ev.push_back(e0); c->ev.push_back(e1);
+    }
+    hipEventRecord(c->ev[c->ev_used], c->stream);
+    c->ev_used += 2;
+    c->ev_class.push_back(cls);
 }
 static void rec_end(fs3d_ctx *c)
 {
     if (!c->timing) return;
-    hipEventRecord(c->ev.back(), c->stream);
+    hipEventRecord(c->ev[c->ev_used - 1], c->stream);
 }
+// accumulates into t_ms/t_n (reset with fs3d_enable_timing)
 static void rec_collect(fs3d_ctx *c)
 {
-    for (int k = 0; k < 4; k++) { c->t_ms[k] = 0; c->t_n[k] = 0; }
     for (size_t i = 0; i < c->ev_class.size(); i++) {
         float ms = 0;
         hipEventSynchronize(c->ev[2 * i + 1]);
         hipEventElapsedTime(&ms, c->ev[2 * i], c->ev[2 * i + 1]);
         c->t_ms[c->ev_class[i]] += ms; c->t_n[c->ev_class[i]]++;
-        hipEventDestroy(c->ev[2 * i]); hipEventDestroy(c->ev[2 * i + 1]);
     }
-    c->ev.clear(); c->ev_class.clear();
+    c->ev_used = 0; c->ev_class.clear();
 }
 
 // ---------------------------------------------------------------------------------
@@ -208,11 +213,11 @@ extern "C" fs3d_status fs3d_create(fs3d_ctx **out, int device, fs3d_precision pr
     CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     // every field = haloSize + dimx*dimy*dimz + haloSize elements, data at +haloSize
     // (TimeLayer3D.h:354, GPUplan.h:79-108), zero-initialised
-    const size_t fbytes = (size_t)(c->ncell + 2 * c->plane) * c->esize;
-    for (int l = 0; l < 5; l++)
-        for (int v = 0; v < 4; v++) { CK(hipMalloc(&c->lay[l][v], fbytes)); CK(hipMemsetAsync(c->lay[l][v], 0, fbytes, c->stream)); }
+    c->fstride = c->ncell + 2 * c->plane;
+    const size_t lbytes = (size_t)4 * c->fstride * c->esize;
+    for (int l = 0; l < 5; l++) { CK(hipMalloc(&c->lay[l], lbytes)); CK(hipMemsetAsync(c->lay[l], 0, lbytes, c->stream)); }
     CK(hipMalloc((void **)&c->code, (size_t)c->ncell * sizeof(uint16_t)));
-    for (int v = 0; v < 4; v++) CK(hipMalloc(&c->node[v], (size_t)c->ncell * c->esize));
+    CK(hipMalloc(&c->node, (size_t)4 * c->ncell * c->esize));
     c->red_blocks = 1024;
     CK(hipMalloc((void **)&c->red_buf, sizeof(double) * 2 * (c->red_blocks + 1)));
     CK(hipHostMalloc((void **)&c->red_host, sizeof(double) * 2, hipHostMallocDefault));
@@ -228,10 +233,11 @@ extern "C" void fs3d_destroy(fs3d_ctx *c)
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     fs3d_comm_destroy(c);
-    for (int l = 0; l < 5; l++) for (int v = 0; v < 4; v++) if (c->lay[l][v]) hipFree(c->lay[l][v]);
+    for (int l = 0; l < 5; l++) if (c->lay[l]) hipFree(c->lay[l]);
     if (c->code) hipFree(c->code);
-    for (int v = 0; v < 4; v++) { if (c->node[v]) hipFree(c->node[v]); if (c->bnd_val[v]) hipFree(c->bnd_val[v]); }
-    for (int v = 0; v < 6; v++) if (c->scr[v]) hipFree(c->scr[v]);
+    if (c->node) hipFree(c->node);
+    if (c->scr) hipFree(c->scr);
+    for (int v = 0; v < 4; v++) if (c->bnd_val[v]) hipFree(c->bnd_val[v]);
     if (c->bnd_idx) hipFree(c->bnd_idx);
     if (c->red_buf) hipFree(c->red_buf);
     if (c->red_host) hipHostFree(c->red_host);
@@ -259,7 +265,13 @@ extern "C" fs3d_status fs3d_set_option(fs3d_ctx *c, int option, int value)
     }
 }
 
-extern "C" fs3d_status fs3d_enable_timing(fs3d_ctx *c, int on) { if (!c) return FS3D_ERR_INVALID; c->timing = on != 0; return FS3D_OK; }
+extern "C" fs3d_status fs3d_enable_timing(fs3d_ctx *c, int on)
+{
+    if (!c) return FS3D_ERR_INVALID;
+    c->timing = on != 0;
+    for (int k = 0; k < 4; k++) { c->t_ms[k] = 0; c->t_n[k] = 0; }
+    return FS3D_OK;
+}
 
 extern "C" fs3d_status fs3d_last_step_timing(fs3d_ctx *c, float ms[4], int n[4])
 {
@@ -363,7 +375,7 @@ static fs3d_status upload_nodes_impl(fs3d_ctx *c, const uint8_t *type, const uin
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpy(c->code, code.data(), code.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     for (int v = 0; v < 4; v++)
-        HIPCHK(c, hipMemcpy(c->node[v], nv[v].data(), (size_t)c->ncell * sizeof(R), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy((R *)c->node + (size_t)v * c->ncell, nv[v].data(), (size_t)c->ncell * sizeof(R), hipMemcpyHostToDevice));
     if (c->bnd_idx) { hipFree(c->bnd_idx); c->bnd_idx = nullptr; }
     for (int v = 0; v < 4; v++) if (c->bnd_val[v]) { hipFree(c->bnd_val[v]); c->bnd_val[v] = nullptr; }
     c->n_bnd = (int)bidx.size();
@@ -405,12 +417,12 @@ extern "C" fs3d_status fs3d_init_layers_from_nodes(fs3d_ctx *c)
     if (!c) return FS3D_ERR_INVALID;
     if (!c->have_nodes) return fail(c, FS3D_ERR_INVALID, "fs3d_init_layers_from_nodes: upload nodes first");
     HIPCHK(c, hipSetDevice(c->device));
-    const size_t fbytes = (size_t)(c->ncell + 2 * c->plane) * c->esize;
-    for (int l = 0; l < 5; l++) for (int v = 0; v < 4; v++) HIPCHK(c, hipMemsetAsync(c->lay[l][v], 0, fbytes, c->stream));
+    const size_t lbytes = (size_t)4 * c->fstride * c->esize;
+    for (int l = 0; l < 5; l++) HIPCHK(c, hipMemsetAsync(c->lay[l], 0, lbytes, c->stream));
     for (int l = 0; l < 4; l++) c->slot[l] = l;
     c->spare = 4;
     for (int v = 0; v < 4; v++)
-        HIPCHK(c, hipMemcpyAsync((char *)c->lay[c->slot[FS3D_LAYER_CUR]][v] + c->plane * c->esize, c->node[v],
+        HIPCHK(c, hipMemcpyAsync(fptr(c, c->slot[FS3D_LAYER_CUR], v), (char *)c->node + (size_t)v * c->ncell * c->esize,
                                  (size_t)c->ncell * c->esize, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return FS3D_OK;
@@ -424,7 +436,7 @@ extern "C" fs3d_status fs3d_upload_layer(fs3d_ctx *c, int layer, const void *u, 
     const void *src[4] = {u, v, w, T};
     for (int k = 0; k < 4; k++)
         if (src[k])
-            HIPCHK(c, hipMemcpyAsync((char *)c->lay[c->slot[layer]][k] + c->plane * c->esize, src[k],
+            HIPCHK(c, hipMemcpyAsync(fptr(c, c->slot[layer], k), src[k],
                                      (size_t)c->ncell * c->esize, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return FS3D_OK;
@@ -438,7 +450,7 @@ extern "C" fs3d_status fs3d_download_layer(fs3d_ctx *c, int layer, void *u, void
     void *dst[4] = {u, v, w, T};
     for (int k = 0; k < 4; k++)
         if (dst[k])
-            HIPCHK(c, hipMemcpyAsync(dst[k], (char *)c->lay[c->slot[layer]][k] + c->plane * c->esize,
+            HIPCHK(c, hipMemcpyAsync(dst[k], fptr(c, c->slot[layer], k),
                                      (size_t)c->ncell * c->esize, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return FS3D_OK;
@@ -448,7 +460,7 @@ extern "C" fs3d_status fs3d_field_dev_ptr(fs3d_ctx *c, int layer, int var, void 
 {
     if (!c || !dev_ptr) return FS3D_ERR_INVALID;
     if (check_layer(c, layer) || var < 0 || var > 3) return fail(c, FS3D_ERR_INVALID, "bad layer/var id");
-    *dev_ptr = (char *)c->lay[c->slot[layer]][var] + c->plane * c->esize;
+    *dev_ptr = fptr(c, c->slot[layer], var);
     return FS3D_OK;
 }
 
@@ -460,12 +472,10 @@ template <typename R>
 static void fill_params(fs3d_ctx *c, SweepParams<R> &p, int dir, double dt_, int b_cur, int b_temp, int b_next, int b_tout, int merge)
 {
     p.dimx = c->dimx; p.dimy = c->dimy; p.dimz = c->dimz; p.plane = c->plane;
-    for (int v = 0; v < 4; v++) {
-        p.cur[v] = fld<R>(c, b_cur, v); p.temp[v] = fld<R>(c, b_temp, v);
-        p.next[v] = fld<R>(c, b_next, v); p.temp_out[v] = fld<R>(c, b_tout, v);
-        p.node[v] = (const R *)c->node[v];
-    }
-    for (int v = 0; v < 6; v++) p.scr[v] = (R *)c->scr[v];
+    p.cur_ = fld<R>(c, b_cur, 0); p.temp_ = fld<R>(c, b_temp, 0);
+    p.next_ = fld<R>(c, b_next, 0); p.temp_out_ = fld<R>(c, b_tout, 0);
+    p.fstride = c->fstride;
+    p.node_ = (const R *)c->node; p.scr_ = (R *)c->scr; p.nstride = c->ncell;
     p.code = c->code;
     // every constant below is evaluated in FTYPE exactly as the reference writes it
     const R dx = (R)c->gdx, dy = (R)c->gdy, dz = (R)c->gdz;          // TimeLayer3D.h:1078-1080
@@ -483,8 +493,8 @@ static void fill_params(fs3d_ctx *c, SweepParams<R> &p, int dir, double dt_, int
 
 static fs3d_status ensure_scratch(fs3d_ctx *c)
 {
-    if (c->scr[0]) return FS3D_OK;
-    for (int v = 0; v < 6; v++) HIPCHK(c, hipMalloc(&c->scr[v], (size_t)c->ncell * c->esize));
+    if (c->scr) return FS3D_OK;
+    HIPCHK(c, hipMalloc(&c->scr, (size_t)6 * c->ncell * c->esize));
     return FS3D_OK;
 }
 

@@ -37,7 +37,7 @@ __device__ __forceinline__ void build_interior_row(const SweepParams<R> &p, long
     constexpr int M2 = DIR == 2 ? 1 : 2;
     const long long sm1 = M1 == 0 ? sx : sy;
     const long long sm2 = M2 == 1 ? sy : sz;
-    const R *tS = p.temp[DIR];
+    const R *tS = p.temp(DIR);
     const R two_ds = p.two_ds[DIR];
 
     const R q = tS[idx] / two_ds;               // temp->Vs->elem / (2*ds)
@@ -45,10 +45,10 @@ __device__ __forceinline__ void build_interior_row(const SweepParams<R> &p, long
     r.a_t = -q - p.vis_t;  r.b_t = p.b_t;  r.c_t = q - p.vis_t;
 
     // derivatives along the sweep axis of U,V,W (for DissFunc) and of T (momentum RHS)
-    const R g0 = (p.temp[0][idx + ss] - p.temp[0][idx - ss]) / two_ds;
-    const R g1 = (p.temp[1][idx + ss] - p.temp[1][idx - ss]) / two_ds;
-    const R g2 = (p.temp[2][idx + ss] - p.temp[2][idx - ss]) / two_ds;
-    const R gT = (p.temp[3][idx + ss] - p.temp[3][idx - ss]) / two_ds;
+    const R g0 = (p.temp(0)[idx + ss] - p.temp(0)[idx - ss]) / two_ds;
+    const R g1 = (p.temp(1)[idx + ss] - p.temp(1)[idx - ss]) / two_ds;
+    const R g2 = (p.temp(2)[idx + ss] - p.temp(2)[idx - ss]) / two_ds;
+    const R gT = (p.temp(3)[idx + ss] - p.temp(3)[idx - ss]) / two_ds;
     // derivatives of the advecting component along the two other axes
     const R x1 = (tS[idx + sm1] - tS[idx - sm1]) / p.two_ds[M1];
     const R x2 = (tS[idx + sm2] - tS[idx - sm2]) / p.two_ds[M2];
@@ -60,11 +60,11 @@ __device__ __forceinline__ void build_interior_row(const SweepParams<R> &p, long
     const R gm2 = M2 == 1 ? g1 : g2;
     const R diss = (((t0 + t1) + t2) + gm1 * x1) + gm2 * x2;
 
-    r.d[0] = p.cur[0][idx] * R(3) / p.dt;
-    r.d[1] = p.cur[1][idx] * R(3) / p.dt;
-    r.d[2] = p.cur[2][idx] * R(3) / p.dt;
+    r.d[0] = p.cur(0)[idx] * R(3) / p.dt;
+    r.d[1] = p.cur(1)[idx] * R(3) / p.dt;
+    r.d[2] = p.cur(2)[idx] * R(3) / p.dt;
     r.d[DIR] = r.d[DIR] - p.v_T * gT;
-    r.d[3] = p.cur[3][idx] * R(3) / p.dt + p.t_phi * diss;
+    r.d[3] = p.cur(3)[idx] * R(3) / p.dt + p.t_phi * diss;
 }
 
 // START / END rows: ApplyBC0 / ApplyBC1, AdiSolver3D.cpp:804-852.
@@ -78,14 +78,14 @@ __device__ __forceinline__ void build_bc_row(const SweepParams<R> &p, long long 
         r.d[0] = r.d[1] = r.d[2] = R(0);
     } else {
         r.a_v = R(0); r.b_v = R(1); r.c_v = R(0);
-        r.d[0] = p.node[0][idx]; r.d[1] = p.node[1][idx]; r.d[2] = p.node[2][idx];
+        r.d[0] = p.node(0)[idx]; r.d[1] = p.node(1)[idx]; r.d[2] = p.node(2)[idx];
     }
     if (tfree) {
         r.a_t = is_start ? R(0) : R(-1); r.b_t = R(2); r.c_t = is_start ? R(-1) : R(0);
         r.d[3] = R(0);
     } else {
         r.a_t = R(0); r.b_t = R(1); r.c_t = R(0);
-        r.d[3] = p.node[3][idx];
+        r.d[3] = p.node(3)[idx];
     }
 }
 

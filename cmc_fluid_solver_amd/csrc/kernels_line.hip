@@ -33,8 +33,8 @@ __global__ void __launch_bounds__(256) k_sweep_line(SweepParams<R> p)
         if (kind == ROW_INTERIOR) build_interior_row<R, DIR>(p, idx, r);
         else if (kind != ROW_SKIP) build_bc_row<R>(p, idx, code, r);
         thomas_forward<R>(kind, r, cp_v, cp_t, dp);
-        p.scr[0][idx] = cp_v; p.scr[1][idx] = cp_t;
-        p.scr[2][idx] = dp[0]; p.scr[3][idx] = dp[1]; p.scr[4][idx] = dp[2]; p.scr[5][idx] = dp[3];
+        p.scr(0)[idx] = cp_v; p.scr(1)[idx] = cp_t;
+        p.scr(2)[idx] = dp[0]; p.scr(3)[idx] = dp[1]; p.scr(4)[idx] = dp[2]; p.scr(5)[idx] = dp[3];
     }
     // back-substitution: x[n-1] = d'[n-1]; x[i] = d'[i] - c'[i]*x[i+1]
     R x[4] = {R(0), R(0), R(0), R(0)};
@@ -42,29 +42,29 @@ __global__ void __launch_bounds__(256) k_sweep_line(SweepParams<R> p)
         const long long idx = base + s * stride;
         const int cw = p.code[idx];
         const int kind = (cw >> (4 * DIR)) & 3;
-        const R c_v = p.scr[0][idx], c_t = p.scr[1][idx];
-        const R d0 = p.scr[2][idx], d1 = p.scr[3][idx], d2 = p.scr[4][idx], d3 = p.scr[5][idx];
+        const R c_v = p.scr(0)[idx], c_t = p.scr(1)[idx];
+        const R d0 = p.scr(2)[idx], d1 = p.scr(3)[idx], d2 = p.scr(4)[idx], d3 = p.scr(5)[idx];
         if (kind == ROW_END || kind == ROW_SKIP) { x[0] = d0; x[1] = d1; x[2] = d2; x[3] = d3; }
         else {
             x[0] = d0 - c_v * x[0]; x[1] = d1 - c_v * x[1];
             x[2] = d2 - c_v * x[2]; x[3] = d3 - c_t * x[3];
         }
         if (kind != ROW_SKIP) {
-            p.next[0][idx] = x[0]; p.next[1][idx] = x[1]; p.next[2][idx] = x[2]; p.next[3][idx] = x[3];
+            p.next(0)[idx] = x[0]; p.next(1)[idx] = x[1]; p.next(2)[idx] = x[2]; p.next(3)[idx] = x[3];
         }
         if (p.merge) {
             const bool is_in = ((cw >> CODE_TYPE_SHIFT) & 3) == FS3D_NODE_IN;
 #pragma unroll
             for (int v = 0; v < 4; v++) {
-                R t = p.temp[v][idx];
+                R t = p.temp(v)[idx];
                 if (is_in) {
                     // NODE_IN cell outside every segment (run without a closing cell,
                     // Grid3D.cpp:87-117): the reference merges the stale `next` value
-                    const R xv = kind != ROW_SKIP ? x[v] : p.next[v][idx];
+                    const R xv = kind != ROW_SKIP ? x[v] : p.next(v)[idx];
                     t = (t + xv) / R(2);
                     if (p.merge == 2) t = (t + xv) / R(2);
                 }
-                p.temp_out[v][idx] = t;
+                p.temp_out(v)[idx] = t;
             }
         }
     }

@@ -35,9 +35,26 @@ def build(force=False):
     return so
 
 
+def _cap_threads():
+    """The GPU box exposes every host core but grants a 16-core share: an uncapped OpenMP team
+    oversubscribes it badly.  Cap the team before libgomp initialises."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(16, n))))
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
+
+def num_threads():
+    _cap_threads()
+    return int(os.environ["OMP_NUM_THREADS"])
+
+
 def lib():
     global _LIB
     if _LIB is None:
+        _cap_threads()
         _LIB = C.CDLL(build())
         for sfx, ct in (("f32", C.c_float), ("f64", C.c_double)):
             P = C.POINTER(ct)

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 DT = 0.1
 PARAMS = (200.0, 0.72, 1.4)
-KERNELS = [capi.SWEEP_LINE, capi.SWEEP_AUTO]
+KERNELS = [capi.SWEEP_LINE, capi.SWEEP_PIPE]
 
 
 def _oracle():
@@ -203,3 +203,39 @@ def test_thin_noslip_wall_shared_cell(built):
             s.UpdateBoundaries(); o.update_boundaries()
             s.TimeStep(DT, 4, 2, True); o.time_step(DT, 4, 2, True)
         assert_layers_equal(s, o, capi.LAYER_CUR, O.L_CUR, "cur")
+
+
+@pytest.mark.parametrize("dims", [(256, 12, 70), (12, 256, 70), (10, 70, 256), (200, 130, 66)])
+def test_long_lines_pipe_kernel(built, dims):
+    """Lines of up to 256 cells (the 32-cells-per-wave instantiation of the pipelined kernel),
+    lane tiles that are partly empty (70 = 64 + 6), obstacle inside: 2 steps, fp32, bit-exact."""
+    O = _oracle()
+    g = grids.box_with_obstacle(*dims, h=0.02)
+    s, o = make_pair(g, np.float32, capi.SWEEP_AUTO)
+    seed_state(s, o, g, np.float32)
+    for d in range(3):
+        s.sweep(d, DT, capi.LAYER_CUR, capi.LAYER_TEMP, capi.LAYER_NEXT, merge=True)
+        o.sweep(d, DT, O.L_CUR, O.L_TEMP, O.L_NEXT); o.merge(O.L_NEXT, O.L_TEMP)
+        assert_layers_equal(s, o, capi.LAYER_NEXT, O.L_NEXT, "next, dir %d" % d)
+        assert_layers_equal(s, o, capi.LAYER_TEMP, O.L_TEMP, "temp, dir %d" % d)
+    for step in range(2):
+        s.UpdateBoundaries(); o.update_boundaries()
+        e = s.TimeStep(DT, 4, 2, True); rc, eo = o.time_step(DT, 4, 2, True)
+        assert e == pytest.approx(eo, rel=1e-12)
+    assert_layers_equal(s, o, capi.LAYER_CUR, O.L_CUR, "cur")
+
+
+def test_pipe_kernel_is_really_used(built):
+    """FS3D_SWEEP_PIPE must not silently fall back: it errors on dims it cannot take."""
+    g = grids.box(12, 12, 300, h=0.02)      # 300-cell Z lines: longer than 8 waves x 32 cells
+    s, o = make_pair(g, np.float32, capi.SWEEP_PIPE)
+    s.sweep(0, DT, capi.LAYER_CUR, capi.LAYER_TEMP, capi.LAYER_NEXT)      # X lines (12) are fine
+    with pytest.raises(capi.Fs3dError) as ei:
+        s.sweep(2, DT, capi.LAYER_CUR, capi.LAYER_TEMP, capi.LAYER_NEXT)
+    assert ei.value.status == capi.ERR_UNSUPPORTED
+    # AUTO falls back to the thread-per-line kernel and still matches
+    s2, o2 = make_pair(g, np.float32, capi.SWEEP_AUTO)
+    O = _oracle()
+    s2.sweep(2, DT, capi.LAYER_CUR, capi.LAYER_TEMP, capi.LAYER_NEXT)
+    o2.sweep(2, DT, O.L_CUR, O.L_TEMP, O.L_NEXT)
+    assert_layers_equal(s2, o2, capi.LAYER_NEXT, O.L_NEXT, "next (fallback)")
