@@ -45,6 +45,7 @@ SYMBOLS = {
     "fs3d_comm_init": (_i, [_vp, _vp, _i, _i]),
     "fs3d_last_step_timing": (_i, [_vp, C.POINTER(C.c_float), C.POINTER(_i)]),
     "fs3d_enable_timing": (_i, [_vp, _i]),
+    "fs3d_profile_sweep": (_i, [_vp, _i, _d, _i, _i, _i, C.POINTER(C.c_ulonglong), _i, C.POINTER(_i)]),
     "fs3d_version": (C.c_char_p, []),
 }
 
@@ -174,6 +175,14 @@ class Solver:
         for a in arrs:
             assert a is None or a.shape == tuple(self.dims)
         self._chk(self.lib.fs3d_upload_layer(self.h, layer, *[_p(a) for a in arrs]))
+
+    def profile_sweep(self, d, dt, l_cur=LAYER_CUR, l_temp=LAYER_TEMP, l_next=LAYER_NEXT, max_blocks=4096):
+        """[blocks, 8 waves, 8 stamps] shader-clock stamps of one pipelined sweep (measurement aid)."""
+        buf = np.zeros((max_blocks, 8, 8), dtype=np.uint64)   # up to 8 waves per workgroup (unused waves stay 0)
+        nb = C.c_int(0)
+        self._chk(self.lib.fs3d_profile_sweep(self.h, d, dt, l_cur, l_temp, l_next,
+                                              buf.ctypes.data_as(C.POINTER(C.c_ulonglong)), max_blocks, C.byref(nb)))
+        return buf[:nb.value]
 
     def enable_timing(self, on=True):
         self._chk(self.lib.fs3d_enable_timing(self.h, int(on)))

@@ -49,6 +49,7 @@ struct SweepParams {
     R b_v, b_t;                 // 3/dt + 2*vis                 (AdiSolver3D.cpp:761)
     R dt;
     R v_T, t_phi;
+    unsigned long long *stamps; // measurement only: per-wave phase time stamps (s_memtime), or nullptr
     int merge;                  // 0: write next only; 1: also temp_out = merged; 2: merged twice (sweep merge + global merge)
 };
 
@@ -90,6 +91,8 @@ struct fs3d_ctx {
     std::vector<int> ev_class;
     float t_ms[4] = {0, 0, 0, 0};
     int t_n[4] = {0, 0, 0, 0};
+    unsigned long long *stamps = nullptr;   // device buffer for fs3d_profile_sweep
+    int stamps_cap = 0;
     // comm
     void *comm = nullptr;          // ncclComm_t
     int rank = 0, nranks = 1;

@@ -240,6 +240,7 @@ extern "C" void fs3d_destroy(fs3d_ctx *c)
     for (int v = 0; v < 4; v++) if (c->bnd_val[v]) hipFree(c->bnd_val[v]);
     if (c->bnd_idx) hipFree(c->bnd_idx);
     if (c->red_buf) hipFree(c->red_buf);
+    if (c->stamps) hipFree(c->stamps);
     if (c->red_host) hipHostFree(c->red_host);
     for (auto e : c->ev) hipEventDestroy(e);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -489,6 +490,7 @@ static void fill_params(fs3d_ctx *c, SweepParams<R> &p, int dir, double dt_, int
     p.b_t = 3 / dt + 2 * p.vis_t;
     p.dt = dt; p.v_T = (R)c->v_T; p.t_phi = (R)c->t_phi;
     p.merge = merge;
+    p.stamps = nullptr;
 }
 
 static fs3d_status ensure_scratch(fs3d_ctx *c)
@@ -516,6 +518,40 @@ static fs3d_status sweep_buffers(fs3d_ctx *c, int dir, double dt, int b_cur, int
     }
     rec_end(c);
     HIPCHK(c, hipGetLastError());
+    return FS3D_OK;
+}
+
+// measurement: one pipelined sweep with per-wave phase stamps
+extern "C" fs3d_status fs3d_profile_sweep(fs3d_ctx *c, int dir, double dt, int l_cur, int l_temp, int l_next,
+                                          unsigned long long *stamps_out, int max_blocks, int *n_blocks_out)
+{
+    if (!c || !stamps_out || !n_blocks_out) return FS3D_ERR_INVALID;
+    if (dir < 0 || dir > 2 || check_layer(c, l_cur) || check_layer(c, l_temp) || check_layer(c, l_next) || l_next == l_cur || l_next == l_temp)
+        return fail(c, FS3D_ERR_INVALID, "fs3d_profile_sweep: bad direction or layer id");
+    if (!c->have_nodes || !c->have_params) return fail(c, FS3D_ERR_INVALID, "fs3d_profile_sweep: upload nodes and set params first");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int la = dir == 2 ? c->dimy : c->dimz, n_o = dir == 0 ? c->dimy : c->dimx;
+    const int nb = n_o * ((la + 63) / 64);
+    if (c->stamps_cap < nb) {
+        if (c->stamps) hipFree(c->stamps);
+        HIPCHK(c, hipMalloc((void **)&c->stamps, sizeof(unsigned long long) * 64 * (size_t)nb));
+        c->stamps_cap = nb;
+    }
+    HIPCHK(c, hipMemsetAsync(c->stamps, 0, sizeof(unsigned long long) * 64 * (size_t)nb, c->stream));
+    bool ok;
+    if (c->prec == FS3D_F32) {
+        SweepParams<float> p; fill_params<float>(c, p, dir, dt, c->slot[l_cur], c->slot[l_temp], c->slot[l_next], c->spare, 1);
+        p.stamps = c->stamps; ok = launch_sweep_pipe<float>(c, dir, p);
+    } else {
+        SweepParams<double> p; fill_params<double>(c, p, dir, dt, c->slot[l_cur], c->slot[l_temp], c->slot[l_next], c->spare, 1);
+        p.stamps = c->stamps; ok = launch_sweep_pipe<double>(c, dir, p);
+    }
+    if (!ok) return fail(c, FS3D_ERR_UNSUPPORTED, "fs3d_profile_sweep: pipelined kernel does not support these dims");
+    HIPCHK(c, hipGetLastError());
+    const int nout = nb < max_blocks ? nb : max_blocks;
+    HIPCHK(c, hipMemcpyAsync(stamps_out, c->stamps, sizeof(unsigned long long) * 64 * (size_t)nout, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *n_blocks_out = nout;
     return FS3D_OK;
 }
 

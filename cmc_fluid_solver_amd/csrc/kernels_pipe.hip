@@ -8,23 +8,176 @@
 //   Z sweep    : lanes run along j, a thread's CH cells are contiguous in memory.
 //
 // Phases (bit-exact w.r.t. the sequential reference, Algorithms.h:21-38)
-//   P  all waves, in parallel: load cur/temp (+ neighbours), build the rows (fs3d_rows.h),
-//      keep per cell q,dU,dV,dW in registers and dT in LDS.
+//   P  all waves in parallel, FIELD-MAJOR: one field of the chunk at a time is pulled into a
+//      register array (CH+2 loads in flight per lane), consumed, and its registers recycled.
+//      Z sweep: the chunk is moved as a [64 lines][CH cells] tile in whole 128-byte rows
+//      (16 bytes per lane) and transposed through a padded LDS tile, so HBM sees cache lines.
+//      Result per cell: q, dU, dV, dW in registers, dT in LDS (rows of fs3d_rows.h).
 //   F  forward elimination as a relay: wave 0 eliminates its chunk, hands (c',d') of its
 //      last cell to wave 1 through LDS, ... The recurrence is the reference's, cell by cell;
 //      c'_uvw,d'_U,d'_V,d'_W overwrite the row data in registers, c'_T,d'_T live in LDS.
 //   B  back-substitution as the reverse relay, registers/LDS only: x overwrites c',d'.
-//   O  all waves, in parallel and off the relay's critical path: scatter x to `next`
-//      (UpdateSegment, AdiSolver3D.cpp:707-730) and apply the merge into temp
-//      (TimeLayer3D.h:415-436) in the same pass.
+//   O  all waves in parallel, field-major: scatter x to `next` (UpdateSegment,
+//      AdiSolver3D.cpp:707-730) and apply the merge into temp (TimeLayer3D.h:415-436).
 // Nothing but the 8 input and 8 output words per cell (+2-byte cell code) moves to/from HBM:
 // the 6 words/cell of c',d' that a thread-per-line kernel spills stay on chip (128 VGPRs
 // per lane + 128 KiB LDS per workgroup for a 256-cell fp32 line).
+#include <algorithm>
 #include "fs3d_rows.h"
 
 #define PIPE_NW 8
 
-template <typename R> struct PipeLds { };
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+
+// Raw buffer access: address = descriptor base (4 SGPRs) + soffset (1 SGPR, wave-uniform row) +
+// voffset (1 VGPR, per-lane byte offset).  One SGPR per row instead of a 64-bit pointer, no 64-bit
+// VALU address arithmetic, and a store is masked by an out-of-range voffset instead of a branch.
+template <typename R> struct Buf;
+template <> struct Buf<float> {
+    static __device__ __forceinline__ float ld(rsrc_t r, unsigned vo, unsigned so) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, vo, so, 0)); }
+    static __device__ __forceinline__ void st(rsrc_t r, unsigned vo, unsigned so, float v) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, vo, so, 0); }
+};
+template <> struct Buf<double> {
+    static __device__ __forceinline__ double ld(rsrc_t r, unsigned vo, unsigned so) { return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, vo, so, 0)); }
+    static __device__ __forceinline__ void st(rsrc_t r, unsigned vo, unsigned so, double v) { __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, vo, so, 0); }
+};
+#define BUF_OOB 0xFFFFFFFFu      // voffset >= num_records: the hardware drops the store
+
+// Geometry of one wave's chunk and the accessors for "one field of PC consecutive cells of the chunk".
+// P and O phases walk the chunk in sub-passes of PC cells so that their transient register arrays stay small.
+template <typename R, int DIR, int CH>
+struct Chunk {
+    static constexpr int VW = 16 / sizeof(R);          // elements per 16-byte vector
+    static constexpr int PC = 64 / sizeof(R) < CH ? 64 / sizeof(R) : CH;   // cells per sub-pass (64 bytes of a Z line)
+    static constexpr int NPASS = CH / PC;
+    static constexpr int PR = PC / VW;                 // 16-byte pieces per tile row
+    static constexpr int RPI = 64 / PR;                // tile rows covered by one wave-wide vector access
+    static constexpr int TSTRIDE = PC + 1;             // padded LDS row (conflict-free column access)
+    static constexpr int TILE_ELEMS = 66 * TSTRIDE;    // 64 lines + the line below + the line above
+
+    int n, s0, lane;
+    bool lane_valid;
+    unsigned row0;             // byte offset (inside a field incl. its leading halo plane) of (lane 0, cell 0)
+    unsigned ssb;              // byte stride along the sweep
+    unsigned vob;              // per-lane byte offset, clamped into the tile for lanes past the lane axis: loads are
+                               // UNCONDITIONAL (a predicated load costs a branch and an s_waitcnt vmcnt(0) at its join)
+    unsigned fbytes;           // bytes of one field incl. both halo planes (descriptor range)
+    int dimz, rows_valid;      // Z: row pitch (elements), number of valid tile rows
+    bool zvec;                 // Z: vector/LDS-transposed path usable (dimz % VW == 0)
+    R *tile;                   // Z: this wave's [66][PC+1] LDS tile
+
+    // descriptor of a layer field given the pointer to its first OWNED cell (one halo plane precedes it)
+    __device__ __forceinline__ rsrc_t field(const R *first_owned, long long plane) const
+    {
+        return __builtin_amdgcn_make_buffer_rsrc((void *)(first_owned - plane), 0, (int)fbytes, 0x00020000);
+    }
+    // byte offset of cell s0+t of lane 0, cell index clamped into the line
+    __device__ __forceinline__ unsigned soff(int t) const
+    {
+        int s = s0 + t;
+        s = s < 0 ? 0 : (s > n - 1 ? n - 1 : s);
+        return row0 + (unsigned)s * ssb;
+    }
+    __device__ __forceinline__ bool cell_ok(int t) const { return s0 + t < n; }
+
+    // values of a field (+ uniform byte offset dub) at cells [c0, c0+PC) of the chunk -> out[0..PC).
+    // Cells past the end of the line and lanes past the lane axis receive clamped (valid, meaningless) data.
+    // EDGES (Z only): also fetch the lines just below/above the tile into tile rows 64 and 65.
+    template <bool EDGES = false>
+    __device__ __forceinline__ void load(rsrc_t f, int dub, int c0, R (&out)[PC]) const
+    {
+        __builtin_amdgcn_sched_barrier(0);   // the previous field's consumers stay above this field's loads (register budget)
+        if (DIR == 2 && zvec) {
+            const int piece = lane % PR, rsub = lane / PR;
+            int pos = s0 + c0 + piece * VW;                 // first cell of this lane's 16-byte piece
+            pos = pos > n - VW ? n - VW : pos;
+            u32x4 v[PR], ve;
+#pragma unroll
+            for (int r = 0; r < PR; r++) {
+                int row = r * RPI + rsub;
+                row = row > rows_valid - 1 ? rows_valid - 1 : row;
+                v[r] = __builtin_amdgcn_raw_buffer_load_b128(f, (unsigned)(row * dimz + pos) * (unsigned)sizeof(R), row0 + dub, 0);
+            }
+            if (EDGES) {
+                // lanes [0,PR): the line below the tile (row -1); lanes [PR,2PR): the line above (row rows_valid)
+                const int erow = rsub == 0 ? 0 : rows_valid + 1;
+                ve = __builtin_amdgcn_raw_buffer_load_b128(f, (unsigned)(erow * dimz + pos) * (unsigned)sizeof(R),
+                                                           row0 + dub - (unsigned)dimz * (unsigned)sizeof(R), 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // every load of the field is in flight before the first consumer
+#pragma unroll
+            for (int r = 0; r < PR; r++) {
+                const int row = r * RPI + rsub;
+                R e[VW];
+                __builtin_memcpy(e, &v[r], 16);
+#pragma unroll
+                for (int k = 0; k < VW; k++) tile[row * TSTRIDE + piece * VW + k] = e[k];
+            }
+            if (EDGES && rsub < 2) {
+                R e[VW];
+                __builtin_memcpy(e, &ve, 16);
+#pragma unroll
+                for (int k = 0; k < VW; k++) tile[(64 + rsub) * TSTRIDE + piece * VW + k] = e[k];
+            }
+#pragma unroll
+            for (int t = 0; t < PC; t++) out[t] = tile[lane * TSTRIDE + t];
+        } else {
+#pragma unroll
+            for (int t = 0; t < PC; t++) out[t] = Buf<R>::ld(f, vob, soff(c0 + t) + dub);
+            __builtin_amdgcn_sched_barrier(0);   // every load of the field is in flight before the first consumer
+        }
+    }
+    // the two cells just outside [c0, c0+PC) (clamped into the line)
+    __device__ __forceinline__ void load_halo(rsrc_t f, int c0, R &lo, R &hi) const
+    {
+        lo = Buf<R>::ld(f, vob, soff(c0 - 1));
+        hi = Buf<R>::ld(f, vob, soff(c0 + PC));
+    }
+    // one cell of this lane (any field-relative uniform byte offset)
+    __device__ __forceinline__ R at(rsrc_t f, unsigned so) const { return Buf<R>::ld(f, vob, so); }
+
+    // scatter in[0..PC) to cells [c0, c0+PC) of a field where wmask bit t is set (all: every valid cell is written)
+    __device__ __forceinline__ void store(rsrc_t f, int c0, const R (&in)[PC], unsigned wmask, bool all) const
+    {
+        if (DIR == 2 && zvec && all) {
+            const int piece = lane % PR, rsub = lane / PR;
+            const int pos = s0 + c0 + piece * VW;
+#pragma unroll
+            for (int t = 0; t < PC; t++) tile[lane * TSTRIDE + t] = in[t];
+#pragma unroll
+            for (int r = 0; r < PR; r++) {
+                const int row = r * RPI + rsub;
+                R e[VW];
+#pragma unroll
+                for (int k = 0; k < VW; k++) e[k] = tile[row * TSTRIDE + piece * VW + k];
+                u32x4 v;
+                __builtin_memcpy(&v, e, 16);
+                const bool ok = row < rows_valid && pos < n;
+                __builtin_amdgcn_raw_buffer_store_b128(v, f, ok ? (unsigned)(row * dimz + pos) * (unsigned)sizeof(R) : BUF_OOB, row0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < PC; t++) {
+                const bool ok = lane_valid && cell_ok(c0 + t) && ((wmask >> t) & 1u);
+                Buf<R>::st(f, ok ? vob : BUF_OOB, soff(c0 + t), in[t]);
+            }
+        }
+    }
+    // central difference along the sweep, in place: a[t] <- (a[t+1] - a[t-1]) / two_ds   (TimeLayer3D.h:338-340)
+    __device__ __forceinline__ static void deriv_inplace(R (&a)[PC], R a_lo, R a_hi, R two_ds)
+    {
+        R prev = a_lo;
+#pragma unroll
+        for (int t = 0; t < PC; t++) {
+            const R cur = a[t];
+            const R nxt = t == PC - 1 ? a_hi : a[t == PC - 1 ? t : t + 1];
+            a[t] = (nxt - prev) / two_ds;
+            prev = cur;
+        }
+    }
+};
 
 // one workgroup = one bundle
 template <typename R, int DIR, int CH>
@@ -43,100 +196,193 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
         const int q = nb >> 3, r = nb & 7, x = lb & 7, slot = lb >> 3;
         lb = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + slot;
     }
-    const int tile = lb / n_o, o = lb - tile * n_o;      // tile-major: consecutive ids = consecutive planes
+    const int tile_id = lb / n_o, o = lb - tile_id * n_o;   // tile-major: consecutive ids = consecutive planes
 
     const int n = DIR == 0 ? p.dimx : (DIR == 1 ? p.dimy : p.dimz);
-    const int la_len = DIR == 2 ? p.dimy : p.dimz;       // length of the lane axis
-    const int l = tile * 64 + lane;
-    const bool lane_valid = l < la_len;
-    const long long ss = DIR == 0 ? p.plane : (DIR == 1 ? (long long)p.dimz : 1LL);
+    const int la_len = DIR == 2 ? p.dimy : p.dimz;          // length of the lane axis
+    const int l = tile_id * 64 + lane;
     const long long so = DIR == 0 ? (long long)p.dimz : p.plane;
-    // every address = (field + wave-uniform element offset)[32-bit per-lane offset]: the uniform part
-    // lives in SGPRs, one VGPR serves all accesses (global_load v, v_off, s[base:base+1])
-    const long long ub = DIR == 0 ? (long long)o * p.dimz + tile * 64
-                       : (DIR == 1 ? (long long)o * p.plane + tile * 64 : (long long)o * p.plane + (long long)tile * 64 * p.dimz);
-    const int vo = DIR == 2 ? lane * p.dimz : lane;
-    const int vsl = DIR == 2 ? p.dimz : 1;               // per-lane offset step of a lane-axis neighbour
-    const bool hi_edge = lane == 63 || l + 1 >= la_len;  // right lane neighbour not in this wave
+    const int vsl = DIR == 2 ? p.dimz : 1;                  // per-lane offset step of a lane-axis neighbour
+    const bool hi_edge = lane == 63 || l + 1 >= la_len;     // right lane neighbour not in this wave
     const bool lo_edge = lane == 0;
 
-    // LDS: [n][64] d_T / d'_T, [n][64] c'_T, relay slots
+    // LDS: [NW*CH][64] d_T / d'_T | [NW*CH][64] c'_T (P and O phases: per-wave transposition tiles) | relay
+    constexpr size_t LDS_D = (size_t)PIPE_NW * CH * 64;
+    constexpr size_t LDS_C = (size_t)PIPE_NW * CH * 64 > (size_t)PIPE_NW * Chunk<R, DIR, CH>::TILE_ELEMS
+                                 ? (size_t)PIPE_NW * CH * 64 : (size_t)PIPE_NW * Chunk<R, DIR, CH>::TILE_ELEMS;
     R *ldsD = (R *)smem_raw;
-    R *ldsC = ldsD + (size_t)PIPE_NW * CH * 64;
-    R *relay = ldsC + (size_t)PIPE_NW * CH * 64;       // 6 x 64 forward, reused 4 x 64 backward
+    R *ldsC = ldsD + LDS_D;
+    R *relay = ldsC + LDS_C;                                // 6 x 64 forward, reused 4 x 64 backward
 
-    const int s0 = w * CH;
-    const R *tS = p.temp(DIR);
+    Chunk<R, DIR, CH> ck;
+    ck.n = n; ck.s0 = w * CH; ck.lane = lane; ck.lane_valid = l < la_len;
+    {
+        // wave-uniform element offset of (lane 0, cell 0) from the first owned cell, then + the halo plane
+        const long long ub = DIR == 0 ? (long long)o * p.dimz + tile_id * 64
+                           : (DIR == 1 ? (long long)o * p.plane + tile_id * 64 : (long long)o * p.plane + (long long)tile_id * 64 * p.dimz);
+        ck.row0 = (unsigned)((ub + p.plane) * (long long)sizeof(R));
+        const long long ss = DIR == 0 ? p.plane : (DIR == 1 ? (long long)p.dimz : 1LL);
+        ck.ssb = (unsigned)(ss * (long long)sizeof(R));
+        const int lc = l < la_len ? lane : la_len - 1 - tile_id * 64;   // clamp lanes past the lane axis
+        ck.vob = (unsigned)(DIR == 2 ? lc * p.dimz : lc) * (unsigned)sizeof(R);
+        ck.fbytes = (unsigned)((p.nstride + 2 * p.plane) * (long long)sizeof(R));
+    }
+    ck.dimz = p.dimz;
+    ck.rows_valid = la_len - tile_id * 64 < 64 ? la_len - tile_id * 64 : 64;
+    ck.zvec = (p.dimz % Chunk<R, DIR, CH>::VW) == 0;
+    ck.tile = ldsC + (size_t)w * Chunk<R, DIR, CH>::TILE_ELEMS;
+    static_assert((size_t)PIPE_NW * Chunk<R, DIR, CH>::TILE_ELEMS <= LDS_C, "transposition tiles must fit in the c'_T region");
+    const int s0 = ck.s0;
+    const bool lane_valid = ck.lane_valid;
+    const int sob = (int)(so * (long long)sizeof(R));           // byte step to the neighbouring `o` plane/row
+    const unsigned vslb = (unsigned)vsl * (unsigned)sizeof(R);  // byte step to a lane-axis neighbour
+    // node values / cell codes have no halo plane: same offsets minus one plane
+    const rsrc_t rNode[4] = {
+        __builtin_amdgcn_make_buffer_rsrc((void *)(p.node(0) - p.plane), 0, (int)ck.fbytes, 0x00020000),
+        __builtin_amdgcn_make_buffer_rsrc((void *)(p.node(1) - p.plane), 0, (int)ck.fbytes, 0x00020000),
+        __builtin_amdgcn_make_buffer_rsrc((void *)(p.node(2) - p.plane), 0, (int)ck.fbytes, 0x00020000),
+        __builtin_amdgcn_make_buffer_rsrc((void *)(p.node(3) - p.plane), 0, (int)ck.fbytes, 0x00020000)};
+    const rsrc_t rCode = __builtin_amdgcn_make_buffer_rsrc((void *)(p.code - p.plane), 0, (int)(ck.fbytes / (sizeof(R) / 2)), 0x00020000);
 
-    // per-cell register storage: q -> c'_uvw ; dU,dV,dW -> d'_U,d'_V,d'_W
+    // per-cell register storage: q -> c'_uvw -> x_T ; dU,dV,dW -> d'_U,d'_V,d'_W -> x_U,x_V,x_W
     R st0[CH], st1[CH], st2[CH], st3[CH];
     unsigned cpack[(CH + 7) / 8];
-    unsigned inmask = 0;
+    unsigned long long inmask = 0, segmask = 0, intmask = 0;   // NODE_IN cells; cells on a segment; INTERIOR rows
 #pragma unroll
     for (int i = 0; i < (CH + 7) / 8; i++) cpack[i] = 0;
 
-    // ------------------------------------------------------------------ P: rows
+    // measurement only (fs3d_profile_sweep): 8 s_memtime stamps per wave
+    unsigned long long *stamp = p.stamps ? p.stamps + ((size_t)blockIdx.x * 8 + w) * 8 : nullptr;
+#define STAMP(k) do { if (stamp && lane == 0) stamp[k] = __builtin_amdgcn_s_memtime(); } while (0)
+    STAMP(0);
+
+    // ------------------------------------------------------------------ P: rows, field by field, PC cells per pass
+    typedef Chunk<R, DIR, CH> CK;
+    constexpr int PC = CK::PC;
     {
-        R wU[3], wV[3], wW[3], wT[3];
-        auto ld = [&](const R *f, int s) -> R {
-            return (lane_valid && s >= 0 && s < n) ? (f + (ub + (long long)s * ss))[vo] : R(0);
-        };
-        wU[0] = ld(p.temp(0), s0 - 1); wV[0] = ld(p.temp(1), s0 - 1); wW[0] = ld(p.temp(2), s0 - 1); wT[0] = ld(p.temp(3), s0 - 1);
-        wU[1] = ld(p.temp(0), s0);     wV[1] = ld(p.temp(1), s0);     wW[1] = ld(p.temp(2), s0);     wT[1] = ld(p.temp(3), s0);
+        // cell codes of the whole chunk
 #pragma unroll
         for (int t = 0; t < CH; t++) {
-            const int s = s0 + t;
-            const long long us = ub + (long long)s * ss;      // wave-uniform offset of cell s
-            wU[2] = ld(p.temp(0), s + 1); wV[2] = ld(p.temp(1), s + 1); wW[2] = ld(p.temp(2), s + 1); wT[2] = ld(p.temp(3), s + 1);
-            int cw = 0;
-            if (lane_valid && s < n) cw = (p.code + us)[vo];
+            // unconditional load, then masked arithmetically (a select would be turned back into a branch)
+            int cw = __builtin_amdgcn_raw_buffer_load_b16(rCode, ck.vob / (sizeof(R) / 2), ck.soff(t) / (sizeof(R) / 2), 0);
+            cw &= -(int)(lane_valid && s0 + t < n);
             const int code = (cw >> (4 * DIR)) & 0xF;
-            const int kind = code & 3;
             cpack[t >> 3] |= (unsigned)code << (4 * (t & 7));
-            if (lane_valid && s < n && ((cw >> CODE_TYPE_SHIFT) & 3) == FS3D_NODE_IN) inmask |= 1u << t;
-            const R tc = DIR == 0 ? wU[1] : (DIR == 1 ? wV[1] : wW[1]);     // advecting component at the cell
-            // lane-axis neighbours of tc: neighbouring lanes, real loads at the wave's edges
-            R l_lo = __shfl_up(tc, 1, 64), l_hi = __shfl_down(tc, 1, 64);
-            R q = R(0), d0 = R(0), d1 = R(0), d2 = R(0), d3 = R(0);
-            if (kind == ROW_INTERIOR) {
-                if (lo_edge) l_lo = (tS + us)[vo - vsl];
-                if (hi_edge) l_hi = (tS + us)[vo + vsl];
-                const R o_lo = (tS + (us - so))[vo], o_hi = (tS + (us + so))[vo];
-                const R two_ds = p.two_ds[DIR];
-                constexpr int M1 = DIR == 0 ? 1 : 0;          // axis of the `o` neighbours
-                constexpr int M2 = DIR == 2 ? 1 : 2;          // axis of the lane neighbours
-                q = tc / two_ds;
-                const R g0 = (wU[2] - wU[0]) / two_ds;
-                const R g1 = (wV[2] - wV[0]) / two_ds;
-                const R g2 = (wW[2] - wW[0]) / two_ds;
-                const R gT = (wT[2] - wT[0]) / two_ds;
-                const R x1 = (o_hi - o_lo) / p.two_ds[M1];
-                const R x2 = (l_hi - l_lo) / p.two_ds[M2];
-                const R t0 = DIR == 0 ? (R(2) * g0) * g0 : g0 * g0;
-                const R t1 = DIR == 1 ? (R(2) * g1) * g1 : g1 * g1;
-                const R t2 = DIR == 2 ? (R(2) * g2) * g2 : g2 * g2;
-                const R gm1 = M1 == 0 ? g0 : g1;
-                const R gm2 = M2 == 1 ? g1 : g2;
-                const R diss = (((t0 + t1) + t2) + gm1 * x1) + gm2 * x2;
-                d0 = (p.cur(0) + us)[vo] * R(3) / p.dt;
-                d1 = (p.cur(1) + us)[vo] * R(3) / p.dt;
-                d2 = (p.cur(2) + us)[vo] * R(3) / p.dt;
-                if (DIR == 0) d0 = d0 - p.v_T * gT;
-                if (DIR == 1) d1 = d1 - p.v_T * gT;
-                if (DIR == 2) d2 = d2 - p.v_T * gT;
-                d3 = (p.cur(3) + us)[vo] * R(3) / p.dt + p.t_phi * diss;
-            } else if (kind != ROW_SKIP) {
-                // ApplyBC0/ApplyBC1 right-hand sides (AdiSolver3D.cpp:804-852): node value or 0
-                if (!(code & ROW_VELFREE)) { d0 = (p.node(0) + us)[vo]; d1 = (p.node(1) + us)[vo]; d2 = (p.node(2) + us)[vo]; }
-                if (!(code & ROW_TEMPFREE)) d3 = (p.node(3) + us)[vo];
+            if (((cw >> CODE_TYPE_SHIFT) & 3) == FS3D_NODE_IN && lane_valid && s0 + t < n) inmask |= 1ull << t;
+            if ((code & 3) != ROW_SKIP) segmask |= 1ull << t;
+            if ((code & 3) == ROW_INTERIOR) intmask |= 1ull << t;
+        }
+        const R two_ds = p.two_ds[DIR];
+        constexpr int M1 = DIR == 0 ? 1 : 0;          // axis of the `o` neighbours
+        constexpr int M2 = DIR == 2 ? 1 : 2;          // axis of the lane neighbours
+        const rsrc_t tS = ck.field(p.temp(DIR), p.plane);
+#pragma unroll
+        for (int pass = 0; pass < CK::NPASS; pass++) {
+            const int c0 = pass * PC;
+            R gS[PC], x1[PC], x2[PC];                  // d(Vs)/ds, d(Vs)/d(o axis), d(Vs)/d(lane axis)
+            R q[PC];
+            {
+                // advecting component Vs = temp[DIR]: q, its s-derivative and its lane-axis derivative
+                R a_lo, a_hi;
+                ck.template load<true>(tS, 0, c0, gS);
+                ck.load_halo(tS, c0, a_lo, a_hi);
+#pragma unroll
+                for (int t = 0; t < PC; t++) {
+                    // lane-axis neighbours of Vs.  X/Y: the same rows one element left/right (same cache lines
+                    // as the centre load).  Z: neighbouring lanes; the wave's two edge lanes read the edge rows.
+                    R l_lo, l_hi;
+                    if (DIR == 2 && ck.zvec) {
+                        l_lo = __shfl_up(gS[t], 1, 64); l_hi = __shfl_down(gS[t], 1, 64);
+                        const R e_lo = ck.tile[64 * CK::TSTRIDE + t], e_hi = ck.tile[65 * CK::TSTRIDE + t];
+                        l_lo = lo_edge ? e_lo : l_lo;
+                        l_hi = hi_edge ? e_hi : l_hi;
+                    } else {
+                        l_lo = ck.at(tS, ck.soff(c0 + t) - vslb);
+                        l_hi = ck.at(tS, ck.soff(c0 + t) + vslb);
+                    }
+                    q[t] = ((intmask >> (c0 + t)) & 1ull) ? gS[t] / two_ds : R(0);     // temp->Vs / (2*ds)
+                    x2[t] = (l_hi - l_lo) / p.two_ds[M2];
+                }
+                CK::deriv_inplace(gS, a_lo, a_hi, two_ds);
             }
-            st0[t] = q; st1[t] = d0; st2[t] = d1; st3[t] = d2;
-            ldsD[(size_t)s * 64 + lane] = d3;
-            wU[0] = wU[1]; wU[1] = wU[2]; wV[0] = wV[1]; wV[1] = wV[2];
-            wW[0] = wW[1]; wW[1] = wW[2]; wT[0] = wT[1]; wT[1] = wT[2];
-            // keep the scheduler from hoisting every cell's loads to the top (it would spill):
-            // one cell's ~13 loads x 8 waves x 64 lanes is already ample memory-level parallelism
-            if ((t & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+            {
+                R c[PC];
+                ck.load(tS, sob, c0, x1);
+                ck.load(tS, -sob, c0, c);
+#pragma unroll
+                for (int t = 0; t < PC; t++) x1[t] = (x1[t] - c[t]) / p.two_ds[M1];
+            }
+            // DissFunc{X,Y,Z} (TimeLayer3D.h:554-588): (((tU + tV) + tW) + g_M1*x1) + g_M2*x2, summed in that order
+            R acc[PC];
+#pragma unroll
+            for (int v = 0; v < 3; v++) {
+                R g[PC];
+                if (v == DIR) {
+#pragma unroll
+                    for (int t = 0; t < PC; t++) g[t] = gS[t];
+                } else {
+                    R a_lo, a_hi;
+                    const rsrc_t tv_ = ck.field(p.temp(v), p.plane);
+                    ck.load(tv_, 0, c0, g);
+                    ck.load_halo(tv_, c0, a_lo, a_hi);
+                    CK::deriv_inplace(g, a_lo, a_hi, two_ds);
+                }
+#pragma unroll
+                for (int t = 0; t < PC; t++) {
+                    const R term = v == DIR ? (R(2) * g[t]) * g[t] : g[t] * g[t];
+                    acc[t] = v == 0 ? term : acc[t] + term;
+                    if (v == M1) x1[t] = g[t] * x1[t];
+                    if (v == M2) x2[t] = g[t] * x2[t];
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < PC; t++) acc[t] = p.t_phi * ((acc[t] + x1[t]) + x2[t]);   // t_phi * DissFunc
+            // temperature: gradient along s (momentum RHS, AdiSolver3D.cpp:766/781/796)
+            R gT[PC];
+            {
+                R a_lo, a_hi;
+                const rsrc_t tT = ck.field(p.temp(3), p.plane);
+                ck.load(tT, 0, c0, gT);
+                ck.load_halo(tT, c0, a_lo, a_hi);
+                CK::deriv_inplace(gT, a_lo, a_hi, two_ds);
+#pragma unroll
+                for (int t = 0; t < PC; t++) gT[t] = p.v_T * gT[t];
+            }
+            {
+                // T right-hand side -> LDS
+                R cT[PC];
+                ck.load(ck.field(p.cur(3), p.plane), 0, c0, cT);
+#pragma unroll
+                for (int t = 0; t < PC; t++) {
+                    const int code = (cpack[(c0 + t) >> 3] >> (4 * ((c0 + t) & 7))) & 0xF;
+                    const int kind = code & 3;
+                    R d3 = R(0);
+                    if (kind == ROW_INTERIOR) d3 = cT[t] * R(3) / p.dt + acc[t];
+                    else if (kind != ROW_SKIP && !(code & ROW_TEMPFREE)) d3 = ck.at(rNode[3], ck.soff(c0 + t));   // ApplyBC0/1: node T
+                    ldsD[(size_t)(s0 + c0 + t) * 64 + lane] = d3;
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < 3; v++) {
+                R cV[PC];
+                ck.load(ck.field(p.cur(v), p.plane), 0, c0, cV);
+#pragma unroll
+                for (int t = 0; t < PC; t++) {
+                    const int code = (cpack[(c0 + t) >> 3] >> (4 * ((c0 + t) & 7))) & 0xF;
+                    const int kind = code & 3;
+                    R d = R(0);
+                    if (kind == ROW_INTERIOR) {
+                        d = cV[t] * R(3) / p.dt;
+                        if (v == DIR) d = d - gT[t];
+                    } else if (kind != ROW_SKIP && !(code & ROW_VELFREE)) d = ck.at(rNode[v], ck.soff(c0 + t));   // ApplyBC0/1: node velocity
+                    if (v == 0) st1[c0 + t] = d;
+                    if (v == 1) st2[c0 + t] = d;
+                    if (v == 2) st3[c0 + t] = d;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < PC; t++) st0[c0 + t] = q[t];
+            __builtin_amdgcn_sched_barrier(0);   // pass boundary
         }
     }
 
@@ -144,7 +390,9 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
     // Every wave executes exactly PIPE_NW barriers: w of them waiting for its turn, the rest
     // after its own chunk (straight-line code: the chunk body exists once, outside any
     // data-dependent control flow, so the register arrays are never copied).
+    STAMP(1);
     for (int i = 0; i < w; i++) __syncthreads();
+    STAMP(2);
     {
         R cp_v = R(0), cp_t = R(0), dp[4] = {R(0), R(0), R(0), R(0)};
         if (w > 0) {
@@ -188,15 +436,20 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
             st0[t] = cp_v; st1[t] = dp[0]; st2[t] = dp[1]; st3[t] = dp[2];
             ldsD[(size_t)s * 64 + lane] = dp[3];
             ldsC[(size_t)s * 64 + lane] = cp_t;
+            // stop the scheduler from hoisting every later cell's chain-independent work (coefficient
+            // selects, LDS reads) to the top of the relay turn: that only buys register spills
+            __builtin_amdgcn_sched_barrier(0);
         }
         relay[0 * 64 + lane] = cp_v; relay[1 * 64 + lane] = cp_t;
         relay[2 * 64 + lane] = dp[0]; relay[3 * 64 + lane] = dp[1];
         relay[4 * 64 + lane] = dp[2]; relay[5 * 64 + lane] = dp[3];
     }
+    STAMP(3);
     for (int i = w; i < PIPE_NW; i++) __syncthreads();
 
     // ------------------------------------------------------------------ B: backward relay (registers/LDS only)
     for (int i = 0; i < PIPE_NW - 1 - w; i++) __syncthreads();
+    STAMP(4);
     {
         R x[4] = {R(0), R(0), R(0), R(0)};
         if (w < PIPE_NW - 1) {
@@ -214,44 +467,58 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
             x[0] = e0 - c_v * x[0]; x[1] = e1 - c_v * x[1];   // Algorithms.h:36-37
             x[2] = e2 - c_v * x[2]; x[3] = e3 - c_t * x[3];
             st0[t] = x[3]; st1[t] = x[0]; st2[t] = x[1]; st3[t] = x[2];   // x replaces c',d'
+            if ((t & 3) == 0) __builtin_amdgcn_sched_barrier(0);
         }
         relay[0 * 64 + lane] = x[0]; relay[1 * 64 + lane] = x[1];
         relay[2 * 64 + lane] = x[2]; relay[3 * 64 + lane] = x[3];
     }
-    for (int i = PIPE_NW - 1 - w; i < PIPE_NW - 1; i++) __syncthreads();
+    STAMP(5);
+    // the PIPE_NW-1 hand-off barriers, plus one more: ldsC becomes the transposition tiles again
+    for (int i = PIPE_NW - 1 - w; i < PIPE_NW; i++) __syncthreads();
+    STAMP(6);
 
-    // ------------------------------------------------------------------ O: scatter + merge (all waves in parallel)
-    if (lane_valid) {
+    // ------------------------------------------------------------------ O: scatter + merge, field by field, PC cells per pass
+    {
+        // does every valid cell of the chunk sit on a segment?  (then whole tiles can be stored)
+        const int len = n - s0 < 0 ? 0 : (n - s0 > CH ? CH : n - s0);
+        const unsigned long long chunk_mask = len >= 64 ? ~0ull : ((1ull << len) - 1ull);
+        const bool all_seg = __all((!lane_valid) || ((segmask & chunk_mask) == chunk_mask));
 #pragma unroll
-        for (int t = 0; t < CH; t++) {
-            const int s = s0 + t;
-            if (s < n) {
-                const long long us = ub + (long long)s * ss;
-                const int kind = (cpack[t >> 3] >> (4 * (t & 7))) & 3;
-                const R x0 = st1[t], x1 = st2[t], x2 = st3[t], x3 = st0[t];
-                if (kind != ROW_SKIP) {
-                    (p.next(0) + us)[vo] = x0; (p.next(1) + us)[vo] = x1; (p.next(2) + us)[vo] = x2; (p.next(3) + us)[vo] = x3;
-                }
+        for (int pass = 0; pass < CK::NPASS; pass++) {
+            const int c0 = pass * PC;
+            const unsigned seg_p = (unsigned)(segmask >> c0), in_p = (unsigned)(inmask >> c0);
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                R xv[PC];
+#pragma unroll
+                for (int t = 0; t < PC; t++) xv[t] = v == 0 ? st1[c0 + t] : (v == 1 ? st2[c0 + t] : (v == 2 ? st3[c0 + t] : st0[c0 + t]));
+                const rsrc_t rNext = ck.field(p.next(v), p.plane);
+                ck.store(rNext, c0, xv, seg_p, all_seg);
                 if (p.merge) {
-                    const bool is_in = (inmask >> t) & 1u;
-                    R tv[4] = {(p.temp(0) + us)[vo], (p.temp(1) + us)[vo], (p.temp(2) + us)[vo], (p.temp(3) + us)[vo]};
-                    if (is_in) {
-                        R xv[4] = {x0, x1, x2, x3};
+                    R tv[PC];
+                    ck.load(ck.field(p.temp(v), p.plane), 0, c0, tv);
+                    if (((in_p & ~seg_p) & (PC >= 32 ? 0xFFFFFFFFu : ((1u << PC) - 1u))) != 0) {
                         // NODE_IN cell outside every segment (run without a closing cell,
                         // Grid3D.cpp:87-117): the reference merges the stale `next` value
-                        if (kind == ROW_SKIP) { xv[0] = (p.next(0) + us)[vo]; xv[1] = (p.next(1) + us)[vo]; xv[2] = (p.next(2) + us)[vo]; xv[3] = (p.next(3) + us)[vo]; }
 #pragma unroll
-                        for (int v = 0; v < 4; v++) {
-                            tv[v] = (tv[v] + xv[v]) / R(2);
-                            if (p.merge == 2) tv[v] = (tv[v] + xv[v]) / R(2);
+                        for (int t = 0; t < PC; t++)
+                            if ((in_p >> t) & ~(seg_p >> t) & 1u) xv[t] = ck.at(rNext, ck.soff(c0 + t));
+                    }
+#pragma unroll
+                    for (int t = 0; t < PC; t++) {
+                        if ((in_p >> t) & 1u) {
+                            tv[t] = (tv[t] + xv[t]) / R(2);
+                            if (p.merge == 2) tv[t] = (tv[t] + xv[t]) / R(2);
                         }
                     }
-                    (p.temp_out(0) + us)[vo] = tv[0]; (p.temp_out(1) + us)[vo] = tv[1]; (p.temp_out(2) + us)[vo] = tv[2]; (p.temp_out(3) + us)[vo] = tv[3];
+                    ck.store(ck.field(p.temp_out(v), p.plane), c0, tv, 0xFFFFFFFFu, true);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // 4 cells = 16 loads in flight per lane, no more
         }
     }
+    STAMP(7);
+#undef STAMP
 }
 
 template <typename R, int DIR, int CH>
@@ -260,7 +527,8 @@ static bool launch_one(fs3d_ctx *c, const SweepParams<R> &p)
     const int la_len = DIR == 2 ? p.dimy : p.dimz;
     const int n_o = DIR == 0 ? p.dimy : p.dimx;
     const int n_tiles = (la_len + 63) / 64;
-    const size_t lds = ((size_t)2 * PIPE_NW * CH * 64 + 6 * 64) * sizeof(R);
+    const size_t lds_c = std::max((size_t)PIPE_NW * CH * 64, (size_t)PIPE_NW * Chunk<R, DIR, CH>::TILE_ELEMS);
+    const size_t lds = ((size_t)PIPE_NW * CH * 64 + lds_c + 6 * 64) * sizeof(R);
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void *)k_sweep_pipe<R, DIR, CH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)

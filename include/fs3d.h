@@ -165,6 +165,14 @@ fs3d_status fs3d_last_step_timing(fs3d_ctx *ctx, float ms[4], int n[4]);
 /* enable/disable per-class event timing (adds 2 events per launch; default off) */
 fs3d_status fs3d_enable_timing(fs3d_ctx *ctx, int on);
 
+/* One pipelined sweep (merge fused, result discarded into the spare temp buffer) with
+ * in-kernel time stamps: for each of the first *n_blocks_out (<= max_blocks) workgroups and
+ * each of its 8 waves, 8 shader-clock stamps (start, rows built, relay turn begins, forward
+ * done, backward begins, backward done, relay drained, stores issued).
+ * stamps_out holds max_blocks*64 values.  Measurement aid; no reference counterpart. */
+fs3d_status fs3d_profile_sweep(fs3d_ctx *ctx, int dir, double dt, int l_cur, int l_temp, int l_next,
+                               unsigned long long *stamps_out, int max_blocks, int *n_blocks_out);
+
 /* library / device identification */
 const char *fs3d_version(void);
 
