@@ -83,21 +83,56 @@ def main():
     dt = 0.1                    # every shipped 3D config: duration 10 / time_steps 100 (FluidSolver3D.cpp:196)
     g = grids.box(n, h=h)
     params = capi.fluid_params(dtype, RE, PR, LAMBDA)
-    # x-slab of this rank (GPUplan::splitEven1D, GPUplan.cpp:122-141: even split, remainder to the first ranks)
-    q, r = divmod(n, world)
-    x0 = rank * q + min(rank, r)
-    x1 = x0 + q + (1 if rank < r else 0)
-    s = capi.Solver(g, params, dtype, device=local_rank, x_range=(x0, x1))
-    s.set_option(capi.OPT_SWEEP_KERNEL, args.kernel)
+    from cmc_fluid_solver_amd.slab import slab_range
+
+    def make_solver(grid):
+        """One context per rank on its x-slab; ranks joined by RCCL inside libfs3d_hip.so."""
+        xa, xb = slab_range(grid.dimx, rank, world)
+        sv = capi.Solver(grid, params, dtype, device=local_rank, x_range=(xa, xb))
+        sv.set_option(capi.OPT_SWEEP_KERNEL, args.kernel)
+        if world > 1:
+            uid = torch.zeros(128, dtype=torch.uint8)
+            if rank == 0:
+                buf = (capi.C.c_char * 128)()
+                assert capi.load().fs3d_comm_unique_id(buf) == 0
+                uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+            uid = uid.cuda()
+            dist.broadcast(uid, 0)
+            sv.comm_init(bytes(uid.cpu().numpy().tobytes()), rank, world)
+        return sv, xa, xb
+
+    # multi-GPU self-check (untimed): a 64^3 box stepped on N slabs must equal the single-GPU fields bit for bit
+    mgpu_check = None
     if world > 1:
-        uid = torch.zeros(128, dtype=torch.uint8)
+        gs = grids.box(64, h=1.0 / 63)
+        sv, xa, xb = make_solver(gs)
+        errs = []
+        for i in range(2):
+            sv.UpdateBoundaries()
+            errs.append(sv.TimeStep(dt, NUM_GLOBAL, NUM_LOCAL, True))
+        mine = np.stack(sv.download_layer(capi.LAYER_CUR))                    # [4, nx, 64, 64]
+        pad = np.zeros((4, (64 + world - 1) // world + 1, 64, 64), dtype=dtype)
+        pad[:, :xb - xa] = mine
+        tl = [torch.empty(pad.shape, dtype=torch.float32 if dtype == np.float32 else torch.float64, device="cuda")
+              for _ in range(world)]
+        dist.all_gather(tl, torch.from_numpy(pad).cuda())
+        sv.close()
         if rank == 0:
-            buf = (capi.C.c_char * 128)()
-            assert capi.load().fs3d_comm_unique_id(buf) == 0
-            uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
-        uid = uid.cuda()
-        dist.broadcast(uid, 0)
-        s.comm_init(bytes(uid.cpu().numpy().tobytes()), rank, world)
+            full = np.concatenate([tl[r].cpu().numpy()[:, :slab_range(64, r, world)[1] - slab_range(64, r, world)[0]]
+                                   for r in range(world)], axis=1)
+            s1 = capi.Solver(gs, params, dtype, device=local_rank)
+            errs1 = []
+            for i in range(2):
+                s1.UpdateBoundaries()
+                errs1.append(s1.TimeStep(dt, NUM_GLOBAL, NUM_LOCAL, True))
+            ref = np.stack(s1.download_layer(capi.LAYER_CUR))
+            s1.close()
+            mgpu_check = {"grid": [64, 64, 64], "steps": 2, "fields_bit_identical_to_single_gpu": bool(np.array_equal(full, ref)),
+                          "max_abs_diff": float(np.abs(full - ref).max()),
+                          "div_error_rel_diff": float(abs(errs[-1] - errs1[-1]) / abs(errs1[-1]))}
+        dist.barrier()
+
+    s, x0, x1 = make_solver(g)
 
     def step(i):
         if i % 10 == 0:      # FluidSolver3D.cpp:242: computeError every 10th step
@@ -159,6 +194,8 @@ def main():
                          "step_frac_of_hbm_roofline_1760B": round(
                              (cells * 1760.0 * (esize / 4) * args.steps / sec / 1e9) / (HBM_PEAK_GBS * world), 4)},
         }
+        if mgpu_check is not None:
+            out["multi_gpu_check"] = mgpu_check
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, dt, args.cpu_steps)
         print(json.dumps(out))

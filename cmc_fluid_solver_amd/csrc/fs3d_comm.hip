@@ -40,6 +40,7 @@ extern "C" fs3d_status fs3d_comm_init(fs3d_ctx *c, const void *unique_id_128, in
 void fs3d_comm_destroy(fs3d_ctx *c)
 {
     if (c && c->comm) { ncclCommDestroy((ncclComm_t)c->comm); c->comm = nullptr; }
+    if (c) for (int i = 0; i < 4; i++) if (c->carry[i]) { hipFree(c->carry[i]); c->carry[i] = nullptr; }
 }
 
 fs3d_status fs3d_comm_halo_exchange(fs3d_ctx *c, int buf, int nfields)
@@ -73,5 +74,17 @@ fs3d_status fs3d_comm_allreduce_sum2(fs3d_ctx *c, double *dev2)
 {
     if (c->nranks == 1) return FS3D_OK;
     NCCLCHK(c, ncclAllReduce(dev2, dev2, 2, ncclDouble, ncclSum, (ncclComm_t)c->comm, c->stream));
+    return FS3D_OK;
+}
+
+fs3d_status fs3d_comm_send(fs3d_ctx *c, const void *dev, size_t count, int peer)
+{
+    NCCLCHK(c, ncclSend(dev, count, c->prec == FS3D_F32 ? ncclFloat : ncclDouble, peer, (ncclComm_t)c->comm, c->stream));
+    return FS3D_OK;
+}
+
+fs3d_status fs3d_comm_recv(fs3d_ctx *c, void *dev, size_t count, int peer)
+{
+    NCCLCHK(c, ncclRecv(dev, count, c->prec == FS3D_F32 ? ncclFloat : ncclDouble, peer, (ncclComm_t)c->comm, c->stream));
     return FS3D_OK;
 }

@@ -95,6 +95,7 @@ struct fs3d_ctx {
     int stamps_cap = 0;
     // comm
     void *comm = nullptr;          // ncclComm_t
+    void *carry[4] = {};           // cross-slab X sweep: fwd in/out (6 x plane), bwd in/out (4 x plane)
     int rank = 0, nranks = 1;
     std::string err;
 };
@@ -102,3 +103,5 @@ struct fs3d_ctx {
 // kernels_*.hip
 template <typename R> void launch_sweep_line(fs3d_ctx *c, int dir, const SweepParams<R> &p);
 template <typename R> bool launch_sweep_pipe(fs3d_ctx *c, int dir, const SweepParams<R> &p); // false: dims unsupported
+template <typename R> void launch_xsweep_fwd(fs3d_ctx *c, const SweepParams<R> &p, const void *carry_in, void *carry_out);
+template <typename R> void launch_xsweep_bwd(fs3d_ctx *c, const SweepParams<R> &p, const void *xcarry_in, void *xcarry_out);

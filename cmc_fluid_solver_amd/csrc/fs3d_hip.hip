@@ -91,7 +91,7 @@ template <typename R>
 __global__ void __launch_bounds__(256) k_div_error(const uint16_t *__restrict__ code,
                                                     const R *__restrict__ U, const R *__restrict__ V,
                                                     const R *__restrict__ W, int dimx, int dimy, int dimz,
-                                                    int i_end, R dx, R dy, R dz, double *partial)
+                                                    int i_end, int i_skip0, R dx, R dy, R dz, double *partial)
 {
     const long long plane = (long long)dimy * dimz;
     const long long n = (long long)dimx * plane;
@@ -102,7 +102,7 @@ __global__ void __launch_bounds__(256) k_div_error(const uint16_t *__restrict__ 
         const int j = rem / dimz, k = rem - j * dimz;
         if (i >= i_end || j >= dimy - 1 || k >= dimz - 1) continue;
         if (((code[id] >> CODE_TYPE_SHIFT) & 3) != FS3D_NODE_IN) continue;
-        if (j == 0 || k == 0) continue;   // reference reads out of bounds there; see oracle note
+        if (j == 0 || k == 0 || (i_skip0 && i == 0)) continue;   // reference reads out of bounds there; see oracle note
         const long long a = id, b = id - dimz, c = id - dimz - 1, d = id - 1;   // (j,k) (j-1,k) (j-1,k-1) (j,k-1)
         const long long m = plane;
         const double ex = (double)((U[a] + U[b] + U[c] + U[d] - U[a - m] - U[b - m] - U[c - m] - U[d - m]) * dz * dy) / 4.0;
@@ -500,6 +500,28 @@ static fs3d_status ensure_scratch(fs3d_ctx *c)
     return FS3D_OK;
 }
 
+// Cross-slab X sweep (nranks > 1): forward over the slabs 0 -> R-1, backward R-1 -> 0, carries over RCCL.
+template <typename R>
+static fs3d_status xsweep_multi(fs3d_ctx *c, SweepParams<R> &p)
+{
+    fs3d_status st = ensure_scratch(c);
+    if (st) return st;
+    p.scr_ = (R *)c->scr;
+    const size_t pl = (size_t)c->plane;
+    if (!c->carry[0]) {
+        HIPCHK(c, hipMalloc(&c->carry[0], 6 * pl * c->esize)); HIPCHK(c, hipMalloc(&c->carry[1], 6 * pl * c->esize));
+        HIPCHK(c, hipMalloc(&c->carry[2], 4 * pl * c->esize)); HIPCHK(c, hipMalloc(&c->carry[3], 4 * pl * c->esize));
+    }
+    const bool first = c->rank == 0, last = c->rank == c->nranks - 1;
+    if (!first && (st = fs3d_comm_recv(c, c->carry[0], 6 * pl, c->rank - 1))) return st;
+    launch_xsweep_fwd<R>(c, p, first ? nullptr : c->carry[0], c->carry[1]);
+    if (!last && (st = fs3d_comm_send(c, c->carry[1], 6 * pl, c->rank + 1))) return st;
+    if (!last && (st = fs3d_comm_recv(c, c->carry[2], 4 * pl, c->rank + 1))) return st;
+    launch_xsweep_bwd<R>(c, p, last ? nullptr : c->carry[2], c->carry[3]);
+    if (!first && (st = fs3d_comm_send(c, c->carry[3], 4 * pl, c->rank - 1))) return st;
+    return FS3D_OK;
+}
+
 // one sweep on explicit buffers; merge: 0 none, 1 fused merge, 2 fused merge twice
 template <typename R>
 static fs3d_status sweep_buffers(fs3d_ctx *c, int dir, double dt, int b_cur, int b_temp, int b_next, int b_tout, int merge)
@@ -507,6 +529,13 @@ static fs3d_status sweep_buffers(fs3d_ctx *c, int dir, double dt, int b_cur, int
     SweepParams<R> p;
     fill_params<R>(c, p, dir, dt, b_cur, b_temp, b_next, b_tout, merge);
     rec_begin(c, dir == 2 ? 0 : (dir == 1 ? 1 : 2));
+    if (dir == 0 && c->nranks > 1) {
+        fs3d_status st = xsweep_multi<R>(c, p);
+        rec_end(c);
+        if (st) return st;
+        HIPCHK(c, hipGetLastError());
+        return FS3D_OK;
+    }
     bool done = false;
     if (c->opt_kernel != FS3D_SWEEP_LINE) done = launch_sweep_pipe<R>(c, dir, p);
     if (!done) {
@@ -601,7 +630,7 @@ static fs3d_status div_error_enqueue(fs3d_ctx *c, int layer)
     rec_begin(c, 3);
     hipLaunchKernelGGL((k_div_error<R>), dim3(c->red_blocks), dim3(256), 0, c->stream, c->code,
                        (const R *)fld<R>(c, b, 0), (const R *)fld<R>(c, b, 1), (const R *)fld<R>(c, b, 2),
-                       c->dimx, c->dimy, c->dimz, i_end, (R)c->gdx, (R)c->gdy, (R)c->gdz, c->red_buf + 2);
+                       c->dimx, c->dimy, c->dimz, i_end, c->x_offset == 0 ? 1 : 0, (R)c->gdx, (R)c->gdy, (R)c->gdz, c->red_buf + 2);
     hipLaunchKernelGGL(k_div_final, dim3(1), dim3(256), 0, c->stream, c->red_buf + 2, c->red_blocks, c->red_buf);
     rec_end(c);
     HIPCHK(c, hipGetLastError());

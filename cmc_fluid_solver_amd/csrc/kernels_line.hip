@@ -85,3 +85,96 @@ void launch_sweep_line(fs3d_ctx *c, int dir, const SweepParams<R> &p)
 
 template void launch_sweep_line<float>(fs3d_ctx *, int, const SweepParams<float> &);
 template void launch_sweep_line<double>(fs3d_ctx *, int, const SweepParams<double> &);
+
+// ---------------------------------------------------------------------------------------------
+// Cross-slab X sweep (multi-GPU): the same recurrence cut at slab boundaries.
+// Rank r eliminates planes [0, dimx) of its slab starting from the (c', d') that rank r-1 reached
+// at its last plane (carry_in, 6 values per line; none on rank 0), leaves c', d' of its cells in the
+// HBM scratch and its own last (c', d') in carry_out.  Back-substitution runs the other way with
+// the x of the neighbour's first plane (xcarry_in, 4 values per line; none on the last rank).
+// This is the reference's pipelined Thomas (AdiSolver3D.cu:524-640) with CPU-ordering semantics;
+// cell for cell it performs the single-GPU arithmetic, so slabbed results are bit-identical.
+// Carry layout: [value][line], line = j*dimz + k.
+template <typename R>
+__global__ void __launch_bounds__(256) k_xsweep_fwd(SweepParams<R> p, const R *carry_in, R *carry_out)
+{
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long nlines = p.plane;
+    if (tid >= nlines) return;
+    R cp_v = R(0), cp_t = R(0), dp[4] = {R(0), R(0), R(0), R(0)};
+    if (carry_in) {
+        cp_v = carry_in[0 * nlines + tid]; cp_t = carry_in[1 * nlines + tid];
+        dp[0] = carry_in[2 * nlines + tid]; dp[1] = carry_in[3 * nlines + tid];
+        dp[2] = carry_in[4 * nlines + tid]; dp[3] = carry_in[5 * nlines + tid];
+    }
+    for (int s = 0; s < p.dimx; s++) {
+        const long long idx = tid + s * p.plane;
+        const int code = p.code[idx] & 0xF;
+        const int kind = code & 3;
+        RowUVWT<R> r;
+        if (kind == ROW_INTERIOR) build_interior_row<R, 0>(p, idx, r);
+        else if (kind != ROW_SKIP) build_bc_row<R>(p, idx, code, r);
+        thomas_forward<R>(kind, r, cp_v, cp_t, dp);
+        p.scr(0)[idx] = cp_v; p.scr(1)[idx] = cp_t;
+        p.scr(2)[idx] = dp[0]; p.scr(3)[idx] = dp[1]; p.scr(4)[idx] = dp[2]; p.scr(5)[idx] = dp[3];
+    }
+    carry_out[0 * nlines + tid] = cp_v; carry_out[1 * nlines + tid] = cp_t;
+    carry_out[2 * nlines + tid] = dp[0]; carry_out[3 * nlines + tid] = dp[1];
+    carry_out[4 * nlines + tid] = dp[2]; carry_out[5 * nlines + tid] = dp[3];
+}
+
+template <typename R>
+__global__ void __launch_bounds__(256) k_xsweep_bwd(SweepParams<R> p, const R *xcarry_in, R *xcarry_out)
+{
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long nlines = p.plane;
+    if (tid >= nlines) return;
+    R x[4] = {R(0), R(0), R(0), R(0)};
+    if (xcarry_in) { x[0] = xcarry_in[tid]; x[1] = xcarry_in[nlines + tid]; x[2] = xcarry_in[2 * nlines + tid]; x[3] = xcarry_in[3 * nlines + tid]; }
+    for (int s = p.dimx - 1; s >= 0; s--) {
+        const long long idx = tid + s * p.plane;
+        const int cw = p.code[idx];
+        const int kind = cw & 3;
+        const R c_v = p.scr(0)[idx], c_t = p.scr(1)[idx];
+        const R d0 = p.scr(2)[idx], d1 = p.scr(3)[idx], d2 = p.scr(4)[idx], d3 = p.scr(5)[idx];
+        if (kind == ROW_END || kind == ROW_SKIP) { x[0] = d0; x[1] = d1; x[2] = d2; x[3] = d3; }
+        else {
+            x[0] = d0 - c_v * x[0]; x[1] = d1 - c_v * x[1];
+            x[2] = d2 - c_v * x[2]; x[3] = d3 - c_t * x[3];
+        }
+        if (kind != ROW_SKIP) {
+            p.next(0)[idx] = x[0]; p.next(1)[idx] = x[1]; p.next(2)[idx] = x[2]; p.next(3)[idx] = x[3];
+        }
+        if (p.merge) {
+            const bool is_in = ((cw >> CODE_TYPE_SHIFT) & 3) == FS3D_NODE_IN;
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                R t = p.temp(v)[idx];
+                if (is_in) {
+                    const R xv = kind != ROW_SKIP ? x[v] : p.next(v)[idx];
+                    t = (t + xv) / R(2);
+                    if (p.merge == 2) t = (t + xv) / R(2);
+                }
+                p.temp_out(v)[idx] = t;
+            }
+        }
+    }
+    xcarry_out[tid] = x[0]; xcarry_out[nlines + tid] = x[1]; xcarry_out[2 * nlines + tid] = x[2]; xcarry_out[3 * nlines + tid] = x[3];
+}
+
+template <typename R>
+void launch_xsweep_fwd(fs3d_ctx *c, const SweepParams<R> &p, const void *carry_in, void *carry_out)
+{
+    const unsigned grid = (unsigned)((p.plane + 63) / 64);
+    hipLaunchKernelGGL((k_xsweep_fwd<R>), dim3(grid), dim3(64), 0, c->stream, p, (const R *)carry_in, (R *)carry_out);
+}
+template <typename R>
+void launch_xsweep_bwd(fs3d_ctx *c, const SweepParams<R> &p, const void *xcarry_in, void *xcarry_out)
+{
+    const unsigned grid = (unsigned)((p.plane + 63) / 64);
+    hipLaunchKernelGGL((k_xsweep_bwd<R>), dim3(grid), dim3(64), 0, c->stream, p, (const R *)xcarry_in, (R *)xcarry_out);
+}
+template void launch_xsweep_fwd<float>(fs3d_ctx *, const SweepParams<float> &, const void *, void *);
+template void launch_xsweep_fwd<double>(fs3d_ctx *, const SweepParams<double> &, const void *, void *);
+template void launch_xsweep_bwd<float>(fs3d_ctx *, const SweepParams<float> &, const void *, void *);
+template void launch_xsweep_bwd<double>(fs3d_ctx *, const SweepParams<double> &, const void *, void *);

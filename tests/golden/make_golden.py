@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz.
+
+WHAT THESE FIXTURES ARE: outputs of the CPU oracle (oracle/fs3d_oracle.c, the restatement of the
+reference's CPU path) on small deterministic inputs -- regression pins of the restatement and the
+vectors the GPU parity tests and the golden tests replay.  They are NOT outputs of the reference
+binary: the reference's FluidSolver3D translation units cannot be compiled in this image without
+stand-ins for cuda_runtime.h / libnetcdf ("Oracle"), and the reference ships no golden
+data of its own.  What is pinned to the reference itself is listed in tests/test_oracle_pins.py.
+
+Run from the repo root:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from cmc_fluid_solver_amd import capi, grids  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CASES = {
+    "box_16x14x18": lambda: grids.box(16, 14, 18, h=0.05),
+    "obstacle_20x16x18": lambda: grids.box_with_obstacle(20, 16, 18, h=0.04),
+}
+DT, G, L, STEPS = 0.1, 4, 2, (1, 2, 5)
+
+for name, mk in CASES.items():
+    for dtype in (np.float32, np.float64):
+        g = mk()
+        o = O.Oracle(g, capi.fluid_params(dtype, 200.0, 0.72, 1.4), dtype)
+        out = {"dims": np.array(g.shape), "h": np.array([g.dx]), "dt": np.array([DT]), "GL": np.array([G, L]),
+               "nseg": np.array([o.num_segments(d) for d in range(3)])}
+        errs = []
+        for step in range(1, max(STEPS) + 1):
+            o.update_boundaries()
+            rc, e = o.time_step(DT, G, L, True)
+            assert rc == 0
+            errs.append(e)
+            if step in STEPS:
+                for v, f in zip("uvwT", o.get_layer_fields(O.L_CUR)):
+                    out["%s_step%d" % (v, step)] = f
+        out["err"] = np.array(errs)
+        V, T = o.get_layer()
+        out["getlayer_V"], out["getlayer_T"] = V, T
+        fn = os.path.join(HERE, "%s_%s.npz" % (name, np.dtype(dtype).name))
+        np.savez_compressed(fn, **out)
+        print(fn, os.path.getsize(fn))

@@ -239,3 +239,63 @@ def test_pipe_kernel_is_really_used(built):
     s2.sweep(2, DT, capi.LAYER_CUR, capi.LAYER_TEMP, capi.LAYER_NEXT)
     o2.sweep(2, DT, O.L_CUR, O.L_TEMP, O.L_NEXT)
     assert_layers_equal(s2, o2, capi.LAYER_NEXT, O.L_NEXT, "next (fallback)")
+
+
+@pytest.mark.parametrize("case", ["box_16x14x18", "obstacle_20x16x18"])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_hip_path_reproduces_committed_golden_vectors(built, case, dtype):
+    """The HIP path against tests/golden/*.npz (made by tests/golden/make_golden.py), no oracle in the loop."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "%s_%s.npz" % (case, np.dtype(dtype).name)))
+    dims = tuple(int(d) for d in z["dims"])
+    mk = grids.box if case.startswith("box") else grids.box_with_obstacle
+    g = mk(*dims, h=float(z["h"][0]))
+    s = capi.Solver(g, capi.fluid_params(dtype, *PARAMS), dtype)
+    assert s.num_segments == list(z["nseg"])
+    G, L = [int(v) for v in z["GL"]]
+    for step in range(1, 6):
+        s.UpdateBoundaries()
+        e = s.TimeStep(float(z["dt"][0]), G, L, True)
+        assert e == pytest.approx(float(z["err"][step - 1]), rel=1e-12)
+        if "u_step%d" % step in z:
+            for v, f in zip("uvwT", s.download_layer(capi.LAYER_CUR)):
+                assert np.array_equal(f, z["%s_step%d" % (v, step)])
+    V, T = s.GetLayer()
+    assert np.array_equal(V, z["getlayer_V"]) and np.array_equal(T, z["getlayer_T"])
+
+
+def test_full_size_properties_256(built):
+    """BASELINE size (256^3 fp32), where the oracle is too slow to replay every step: size-independent
+    properties.  (1) the y-mirror symmetry of the box flow (u, w, T even; v odd) is kept to rounding,
+    (2) the divergence error stays in the range the 64^3/128^3 oracle runs show, (3) the pipelined and
+    the thread-per-line kernels give identical fields, (4) two independent runs are bit-identical."""
+    g = grids.box(256, h=1.0 / 255)
+    params = capi.fluid_params(np.float32, *PARAMS)
+    runs = []
+    for kernel in (capi.SWEEP_PIPE, capi.SWEEP_PIPE, capi.SWEEP_LINE):
+        s = capi.Solver(g, params, np.float32)
+        s.set_option(capi.OPT_SWEEP_KERNEL, kernel)
+        for step in range(3):
+            s.UpdateBoundaries()
+            e = s.TimeStep(DT, 4, 2, True)
+        runs.append((e, s.download_layer(capi.LAYER_CUR)))
+        s.close()
+    (e0, f0), (e1, f1), (e2, f2) = runs
+    assert 0 < e0 < 1e-5
+    for a, b, c in zip(f0, f1, f2):
+        assert np.array_equal(a, b) and np.array_equal(a, c)
+    u, v, w, T = f0
+    assert np.abs(u - u[:, ::-1, :]).max() < 1e-5 and np.abs(v + v[:, ::-1, :]).max() < 1e-5
+    assert np.abs(T - T[:, ::-1, :]).max() < 1e-5
+
+
+def test_oracle_spot_check_128_fp64(built):
+    """BASELINE configs[1]: 128^3 fp64 box, one full step against the oracle (bit-exact fields)."""
+    O = _oracle()
+    g = grids.box(128, h=1.0 / 127)
+    s, o = make_pair(g, np.float64)
+    s.UpdateBoundaries(); o.update_boundaries()
+    e = s.TimeStep(DT, 4, 2, True)
+    rc, eo = o.time_step(DT, 4, 2, True)
+    assert rc == 0 and e == pytest.approx(eo, rel=1e-12)
+    assert_layers_equal(s, o, capi.LAYER_CUR, O.L_CUR, "cur")

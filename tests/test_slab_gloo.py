@@ -1,0 +1,83 @@
+"""Multi-rank protocol of the cross-slab X sweep, on CPU with torch.distributed/gloo, world_size 2
+and 3: each rank owns a slab of the lines, forward carries travel rank r -> r+1, back-substitution
+carries r+1 -> r (the order fs3d_hip.hip:xsweep_multi issues its RCCL send/recv).  The slabbed result
+must equal the unsplit Thomas solve (the oracle's, pinned to the reference's Algorithms.h) bit for bit.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from cmc_fluid_solver_amd import slab  # noqa: E402
+
+
+def _make_system(n, nlines, dtype, seed):
+    rng = np.random.default_rng(seed)
+    a = rng.uniform(-1, 1, (n, nlines)).astype(dtype)
+    c = rng.uniform(-1, 1, (n, nlines)).astype(dtype)
+    b = rng.uniform(2.1, 4, (n, nlines)).astype(dtype)
+    d = rng.uniform(-5, 5, (n, nlines)).astype(dtype)
+    a[0] = 0
+    c[n - 1] = 0                      # Algorithms.h:23
+    return a, b, c, d
+
+
+def _worker(rank, world, port, n, nlines, dtype_name, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dtype = np.dtype(dtype_name)
+    tdt = torch.float32 if dtype == np.float32 else torch.float64
+    a, b, c, d = _make_system(n, nlines, dtype, seed=7)          # every rank holds the whole grid (as the reference does)
+    x0, x1 = slab.slab_range(n, rank, world)
+    sl = slice(x0, x1)
+    carry = None
+    if rank > 0:
+        buf = torch.empty((2, nlines), dtype=tdt)
+        dist.recv(buf, src=rank - 1)
+        carry = (buf[0].numpy().copy(), buf[1].numpy().copy())
+    cp, dp, out = slab.thomas_forward_slab(a[sl], b[sl], c[sl], d[sl], carry)
+    if rank < world - 1:
+        dist.send(torch.from_numpy(np.stack(out)), dst=rank + 1)
+    xc = None
+    if rank < world - 1:
+        buf = torch.empty((nlines,), dtype=tdt)
+        dist.recv(buf, src=rank + 1)
+        xc = buf.numpy().copy()
+    x, first = slab.thomas_backward_slab(cp, dp, xc)
+    if rank > 0:
+        dist.send(torch.from_numpy(first), dst=rank - 1)
+    np.save(os.path.join(out_dir, "x_%d.npy" % rank), x)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("dtype_name", ["float32", "float64"])
+def test_slab_pipelined_thomas_equals_unsplit(tmp_path, world, dtype_name):
+    from oracle import oracle as O
+    n, nlines = 37, 24
+    port = 29600 + world * 10 + (0 if dtype_name == "float32" else 1)
+    mp.spawn(_worker, args=(world, port, n, nlines, dtype_name, str(tmp_path)), nprocs=world, join=True)
+    x = np.concatenate([np.load(tmp_path / ("x_%d.npy" % r)) for r in range(world)], axis=0)
+    a, b, c, d = _make_system(n, nlines, np.dtype(dtype_name), seed=7)
+    for line in range(nlines):
+        ref = O.tridiag(a[:, line], b[:, line], c[:, line], d[:, line])
+        assert np.array_equal(x[:, line], ref), "line %d differs from the unsplit solve" % line
+
+
+def test_slab_ranges_cover_the_grid():
+    for dimx in (7, 64, 255, 256):
+        for nr in (1, 2, 3, 8):
+            rs = [slab.slab_range(dimx, r, nr) for r in range(nr)]
+            assert rs[0][0] == 0 and rs[-1][1] == dimx
+            assert all(rs[i][1] == rs[i + 1][0] for i in range(nr - 1))
+            sizes = [b - a for a, b in rs]
+            assert max(sizes) - min(sizes) <= 1
