@@ -27,6 +27,7 @@
 
 #define PIPE_NW 8
 
+
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
@@ -144,18 +145,29 @@ struct Chunk {
         if (DIR == 2 && zvec && all) {
             const int piece = lane % PR, rsub = lane / PR;
             const int pos = s0 + c0 + piece * VW;
+            // HAZARD (observed on gfx950): an LDS read that returns into the VGPRs of a still-queued
+            // 16-byte buffer store corrupts that store's data (the LGKM and VMEM queues are not ordered
+            // against each other and the store fetches its data late).  Drain the stores of the
+            // previous call before this call's LDS reads, and read every row before storing any.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
             for (int t = 0; t < PC; t++) tile[lane * TSTRIDE + t] = in[t];
+            u32x4 v[PR];
 #pragma unroll
             for (int r = 0; r < PR; r++) {
                 const int row = r * RPI + rsub;
                 R e[VW];
 #pragma unroll
                 for (int k = 0; k < VW; k++) e[k] = tile[row * TSTRIDE + piece * VW + k];
-                u32x4 v;
-                __builtin_memcpy(&v, e, 16);
+                __builtin_memcpy(&v[r], e, 16);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < PR; r++) {
+                const int row = r * RPI + rsub;
                 const bool ok = row < rows_valid && pos < n;
-                __builtin_amdgcn_raw_buffer_store_b128(v, f, ok ? (unsigned)(row * dimz + pos) * (unsigned)sizeof(R) : BUF_OOB, row0, 0);
+                // masked lanes: an offset past the descriptor range (and far from wrapping) drops the store
+                __builtin_amdgcn_raw_buffer_store_b128(v[r], f, ok ? (unsigned)(row * dimz + pos) * (unsigned)sizeof(R) : 0x80000000u, row0, 0);
             }
         } else {
 #pragma unroll
@@ -208,8 +220,13 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
 
     // LDS: [NW*CH][64] d_T / d'_T | [NW*CH][64] c'_T (P and O phases: per-wave transposition tiles) | relay
     constexpr size_t LDS_D = (size_t)PIPE_NW * CH * 64;
-    constexpr size_t LDS_C = (size_t)PIPE_NW * CH * 64 > (size_t)PIPE_NW * Chunk<R, DIR, CH>::TILE_ELEMS
-                                 ? (size_t)PIPE_NW * CH * 64 : (size_t)PIPE_NW * Chunk<R, DIR, CH>::TILE_ELEMS;
+    // Per-wave transposition tiles (Z sweep, P and O phases).  A tile must not overlap the c'_T rows of
+    // ANOTHER wave: wave w starts writing its own c'_T rows in its forward turn while later waves may
+    // still be building rows.  If a tile fits into the wave's own c'_T row range it lives there,
+    // otherwise the tiles get a region of their own behind the c'_T rows.
+    constexpr size_t TILE = Chunk<R, DIR, CH>::TILE_ELEMS;
+    constexpr bool TILE_IN_ROWS = TILE <= (size_t)CH * 64;
+    constexpr size_t LDS_C = (size_t)PIPE_NW * CH * 64 + (TILE_IN_ROWS ? 0 : (size_t)PIPE_NW * TILE);
     R *ldsD = (R *)smem_raw;
     R *ldsC = ldsD + LDS_D;
     R *relay = ldsC + LDS_C;                                // 6 x 64 forward, reused 4 x 64 backward
@@ -230,8 +247,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
     ck.dimz = p.dimz;
     ck.rows_valid = la_len - tile_id * 64 < 64 ? la_len - tile_id * 64 : 64;
     ck.zvec = (p.dimz % Chunk<R, DIR, CH>::VW) == 0;
-    ck.tile = ldsC + (size_t)w * Chunk<R, DIR, CH>::TILE_ELEMS;
-    static_assert((size_t)PIPE_NW * Chunk<R, DIR, CH>::TILE_ELEMS <= LDS_C, "transposition tiles must fit in the c'_T region");
+    ck.tile = TILE_IN_ROWS ? ldsC + (size_t)w * CH * 64 : ldsC + (size_t)PIPE_NW * CH * 64 + (size_t)w * TILE;
     const int s0 = ck.s0;
     const bool lane_valid = ck.lane_valid;
     const int sob = (int)(so * (long long)sizeof(R));           // byte step to the neighbouring `o` plane/row
@@ -527,7 +543,8 @@ static bool launch_one(fs3d_ctx *c, const SweepParams<R> &p)
     const int la_len = DIR == 2 ? p.dimy : p.dimz;
     const int n_o = DIR == 0 ? p.dimy : p.dimx;
     const int n_tiles = (la_len + 63) / 64;
-    const size_t lds_c = std::max((size_t)PIPE_NW * CH * 64, (size_t)PIPE_NW * Chunk<R, DIR, CH>::TILE_ELEMS);
+    const size_t tile = Chunk<R, DIR, CH>::TILE_ELEMS;
+    const size_t lds_c = (size_t)PIPE_NW * CH * 64 + (tile <= (size_t)CH * 64 ? 0 : (size_t)PIPE_NW * tile);
     const size_t lds = ((size_t)PIPE_NW * CH * 64 + lds_c + 6 * 64) * sizeof(R);
     static bool attr_set = false;
     if (!attr_set) {

@@ -264,6 +264,27 @@ def test_hip_path_reproduces_committed_golden_vectors(built, case, dtype):
     assert np.array_equal(V, z["getlayer_V"]) and np.array_equal(T, z["getlayer_T"])
 
 
+@pytest.mark.parametrize("d", [0, 1, 2])
+def test_full_size_sweep_kernels_agree_256(built, d):
+    """256^3 fp32, one merged sweep from a seeded state: the pipelined kernel, run twice, and the
+    thread-per-line kernel must give identical `next` and `temp` (races show up only at full occupancy)."""
+    g = grids.box_with_obstacle(256, h=1.0 / 255)
+    params = capi.fluid_params(np.float32, *PARAMS)
+    base = [np.ascontiguousarray(a, np.float32) for a in (g.vx, g.vy, g.vz, g.T)]
+    cur = grids.perturb(base, seed=11); tmp = grids.perturb(base, seed=12)
+    outs = []
+    for kernel in (capi.SWEEP_PIPE, capi.SWEEP_PIPE, capi.SWEEP_LINE):
+        s = capi.Solver(g, params, np.float32)
+        s.set_option(capi.OPT_SWEEP_KERNEL, kernel)
+        s.upload_layer(capi.LAYER_CUR, cur); s.upload_layer(capi.LAYER_TEMP, tmp)
+        s.sweep(d, DT, capi.LAYER_CUR, capi.LAYER_TEMP, capi.LAYER_NEXT, merge=True)
+        outs.append(s.download_layer(capi.LAYER_NEXT) + s.download_layer(capi.LAYER_TEMP))
+        s.close()
+    for k, (a, b, c) in enumerate(zip(*outs)):
+        assert np.array_equal(a, b), "pipelined kernel not reproducible, array %d: %d cells differ" % (k, (a != b).sum())
+        assert np.array_equal(a, c), "pipelined != thread-per-line, array %d: %d cells differ" % (k, (a != c).sum())
+
+
 def test_full_size_properties_256(built):
     """BASELINE size (256^3 fp32), where the oracle is too slow to replay every step: size-independent
     properties.  (1) the y-mirror symmetry of the box flow (u, w, T even; v odd) is kept to rounding,
