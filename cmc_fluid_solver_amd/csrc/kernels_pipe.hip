@@ -26,6 +26,9 @@
 #include "fs3d_rows.h"
 
 #define PIPE_NW 8
+#ifndef FS3D_Z_TILE_STORE
+#define FS3D_Z_TILE_STORE 1   // Z sweep: scatter through the LDS tile in whole 64-byte row pieces
+#endif
 
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -108,22 +111,23 @@ struct Chunk {
                                                            row0 + dub - (unsigned)dimz * (unsigned)sizeof(R), 0);
             }
             __builtin_amdgcn_sched_barrier(0);   // every load of the field is in flight before the first consumer
+            R *const trow = tile + (rsub * TSTRIDE + piece * VW);      // + r*RPI*TSTRIDE + k: immediate offsets
+            R *const tcol = tile + lane * TSTRIDE;
 #pragma unroll
             for (int r = 0; r < PR; r++) {
-                const int row = r * RPI + rsub;
                 R e[VW];
                 __builtin_memcpy(e, &v[r], 16);
 #pragma unroll
-                for (int k = 0; k < VW; k++) tile[row * TSTRIDE + piece * VW + k] = e[k];
+                for (int k = 0; k < VW; k++) trow[r * RPI * TSTRIDE + k] = e[k];
             }
             if (EDGES && rsub < 2) {
                 R e[VW];
                 __builtin_memcpy(e, &ve, 16);
 #pragma unroll
-                for (int k = 0; k < VW; k++) tile[(64 + rsub) * TSTRIDE + piece * VW + k] = e[k];
+                for (int k = 0; k < VW; k++) trow[64 * TSTRIDE + k] = e[k];
             }
 #pragma unroll
-            for (int t = 0; t < PC; t++) out[t] = tile[lane * TSTRIDE + t];
+            for (int t = 0; t < PC; t++) out[t] = tcol[t];
         } else {
 #pragma unroll
             for (int t = 0; t < PC; t++) out[t] = Buf<R>::ld(f, vob, soff(c0 + t) + dub);
@@ -139,35 +143,27 @@ struct Chunk {
     // one cell of this lane (any field-relative uniform byte offset)
     __device__ __forceinline__ R at(rsrc_t f, unsigned so) const { return Buf<R>::ld(f, vob, so); }
 
-    // scatter in[0..PC) to cells [c0, c0+PC) of a field where wmask bit t is set (all: every valid cell is written)
-    __device__ __forceinline__ void store(rsrc_t f, int c0, const R (&in)[PC], unsigned wmask, bool all) const
+    struct Keep { int unused; };
+    static __device__ __forceinline__ void pin(Keep &) {}
+    // scatter in[0..PC) to cells [c0, c0+PC) of a field where wmask bit t is set (all: every valid cell is written).
+    // Z sweep, all cells written: transpose through the LDS tile and store element-wide, each wave-instruction
+    // covering 64/PC whole tile rows of PC contiguous cells (full 64-byte segments).
+    __device__ __forceinline__ void store(rsrc_t f, int c0, const R (&in)[PC], unsigned wmask, bool all, Keep &) const
     {
-        if (DIR == 2 && zvec && all) {
-            const int piece = lane % PR, rsub = lane / PR;
-            const int pos = s0 + c0 + piece * VW;
-            // HAZARD (observed on gfx950): an LDS read that returns into the VGPRs of a still-queued
-            // 16-byte buffer store corrupts that store's data (the LGKM and VMEM queues are not ordered
-            // against each other and the store fetches its data late).  Drain the stores of the
-            // previous call before this call's LDS reads, and read every row before storing any.
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (DIR == 2 && zvec && all && FS3D_Z_TILE_STORE) {
+            constexpr int RPS = 64 / PC;                        // tile rows per store instruction
+            const int col = lane % PC, rsub = lane / PC;
+            R *const tcol = tile + lane * TSTRIDE;
+            R *const trow = tile + (rsub * TSTRIDE + col);
 #pragma unroll
-            for (int t = 0; t < PC; t++) tile[lane * TSTRIDE + t] = in[t];
-            u32x4 v[PR];
+            for (int t = 0; t < PC; t++) tcol[t] = in[t];
+            const bool col_ok = s0 + c0 + col < n;
 #pragma unroll
-            for (int r = 0; r < PR; r++) {
-                const int row = r * RPI + rsub;
-                R e[VW];
-#pragma unroll
-                for (int k = 0; k < VW; k++) e[k] = tile[row * TSTRIDE + piece * VW + k];
-                __builtin_memcpy(&v[r], e, 16);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int r = 0; r < PR; r++) {
-                const int row = r * RPI + rsub;
-                const bool ok = row < rows_valid && pos < n;
-                // masked lanes: an offset past the descriptor range (and far from wrapping) drops the store
-                __builtin_amdgcn_raw_buffer_store_b128(v[r], f, ok ? (unsigned)(row * dimz + pos) * (unsigned)sizeof(R) : 0x80000000u, row0, 0);
+            for (int r = 0; r < PC; r++) {
+                const int row = r * RPS + rsub;
+                const R val = trow[r * RPS * TSTRIDE];
+                const bool ok = col_ok && row < rows_valid;
+                Buf<R>::st(f, ok ? (unsigned)(row * dimz + s0 + c0 + col) * (unsigned)sizeof(R) : BUF_OOB, row0, val);
             }
         } else {
 #pragma unroll
@@ -229,7 +225,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
     constexpr size_t LDS_C = (size_t)PIPE_NW * CH * 64 + (TILE_IN_ROWS ? 0 : (size_t)PIPE_NW * TILE);
     R *ldsD = (R *)smem_raw;
     R *ldsC = ldsD + LDS_D;
-    R *relay = ldsC + LDS_C;                                // 6 x 64 forward, reused 4 x 64 backward
+    R *relay = ldsC + LDS_C;                                // 8 x 64 forward (c', d' per pass), reused 4 x 64 backward
 
     Chunk<R, DIR, CH> ck;
     ck.n = n; ck.s0 = w * CH; ck.lane = lane; ck.lane_valid = l < la_len;
@@ -250,6 +246,9 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
     ck.tile = TILE_IN_ROWS ? ldsC + (size_t)w * CH * 64 : ldsC + (size_t)PIPE_NW * CH * 64 + (size_t)w * TILE;
     const int s0 = ck.s0;
     const bool lane_valid = ck.lane_valid;
+    // this thread's column of the c'_T / d_T arrays: cell t of the chunk is at myX[t * 64] (immediate DS offsets)
+    R *const myD = ldsD + ((size_t)s0 * 64 + lane);
+    R *const myC = ldsC + ((size_t)s0 * 64 + lane);
     const int sob = (int)(so * (long long)sizeof(R));           // byte step to the neighbouring `o` plane/row
     const unsigned vslb = (unsigned)vsl * (unsigned)sizeof(R);  // byte step to a lane-axis neighbour
     // node values / cell codes have no halo plane: same offsets minus one plane
@@ -263,7 +262,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
     // per-cell register storage: q -> c'_uvw -> x_T ; dU,dV,dW -> d'_U,d'_V,d'_W -> x_U,x_V,x_W
     R st0[CH], st1[CH], st2[CH], st3[CH];
     unsigned cpack[(CH + 7) / 8];
-    unsigned long long inmask = 0, segmask = 0, intmask = 0;   // NODE_IN cells; cells on a segment; INTERIOR rows
+    unsigned inmask = 0, segmask = 0, intmask = 0;         // NODE_IN cells; cells on a segment; INTERIOR rows (CH <= 32)
 #pragma unroll
     for (int i = 0; i < (CH + 7) / 8; i++) cpack[i] = 0;
 
@@ -284,9 +283,9 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
             cw &= -(int)(lane_valid && s0 + t < n);
             const int code = (cw >> (4 * DIR)) & 0xF;
             cpack[t >> 3] |= (unsigned)code << (4 * (t & 7));
-            if (((cw >> CODE_TYPE_SHIFT) & 3) == FS3D_NODE_IN && lane_valid && s0 + t < n) inmask |= 1ull << t;
-            if ((code & 3) != ROW_SKIP) segmask |= 1ull << t;
-            if ((code & 3) == ROW_INTERIOR) intmask |= 1ull << t;
+            if (((cw >> CODE_TYPE_SHIFT) & 3) == FS3D_NODE_IN && lane_valid && s0 + t < n) inmask |= 1u << t;
+            if ((code & 3) != ROW_SKIP) segmask |= 1u << t;
+            if ((code & 3) == ROW_INTERIOR) intmask |= 1u << t;
         }
         const R two_ds = p.two_ds[DIR];
         constexpr int M1 = DIR == 0 ? 1 : 0;          // axis of the `o` neighbours
@@ -316,7 +315,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
                         l_lo = ck.at(tS, ck.soff(c0 + t) - vslb);
                         l_hi = ck.at(tS, ck.soff(c0 + t) + vslb);
                     }
-                    q[t] = ((intmask >> (c0 + t)) & 1ull) ? gS[t] / two_ds : R(0);     // temp->Vs / (2*ds)
+                    q[t] = ((intmask >> (c0 + t)) & 1u) ? gS[t] / two_ds : R(0);     // temp->Vs / (2*ds)
                     x2[t] = (l_hi - l_lo) / p.two_ds[M2];
                 }
                 CK::deriv_inplace(gS, a_lo, a_hi, two_ds);
@@ -375,7 +374,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
                     R d3 = R(0);
                     if (kind == ROW_INTERIOR) d3 = cT[t] * R(3) / p.dt + acc[t];
                     else if (kind != ROW_SKIP && !(code & ROW_TEMPFREE)) d3 = ck.at(rNode[3], ck.soff(c0 + t));   // ApplyBC0/1: node T
-                    ldsD[(size_t)(s0 + c0 + t) * 64 + lane] = d3;
+                    myD[(c0 + t) * 64] = d3;
                 }
             }
 #pragma unroll
@@ -402,66 +401,58 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
         }
     }
 
-    // ------------------------------------------------------------------ F: forward relay
-    // Every wave executes exactly PIPE_NW barriers: w of them waiting for its turn, the rest
-    // after its own chunk (straight-line code: the chunk body exists once, outside any
-    // data-dependent control flow, so the register arrays are never copied).
+    // ------------------------------------------------------------------ F: forward relays, staggered
+    // The four right-hand sides (T, U, V, W) are four independent first-order recurrences once each pass
+    // carries its own c' (U, V, W repeat the shared c'_uvw recurrence: same inputs, same operations, same
+    // rounding -> identical values).  Each is a relay over the waves; wave w runs pass k in turn w + k, so
+    // up to four waves (on different SIMDs) advance at the same time and the forward phase takes
+    // PIPE_NW + 3 turns of one short pass instead of PIPE_NW turns of one long one.
+    // Chain body per cell and pass, branch-free (the row kinds only steer selects):
+    //   INTERIOR a = -q - vis, b = 3/dt + 2 vis, c = q - vis      (AdiSolver3D.cpp:760-762)
+    //   START    a = 0,  FREE: b = 2, c = -1 ; NOSLIP: b = 1, c = 0 (ApplyBC0, :804-827)
+    //   END      c = 0,  FREE: a = -1, b = 2 ; NOSLIP: a = 0, b = 1 (ApplyBC1, :829-852)
+    //   SKIP     identity row.  START and SKIP rows restart the recurrence: the carried c', d' are
+    //   zeroed first, which makes the general step  c' = c/(b - a c'), d' = (d - d' a)/(b - a c')
+    //   (Algorithms.h:28-32) equal to c0/b0, d0/b0 exactly.
     STAMP(1);
     for (int i = 0; i < w; i++) __syncthreads();
     STAMP(2);
-    {
-        R cp_v = R(0), cp_t = R(0), dp[4] = {R(0), R(0), R(0), R(0)};
-        if (w > 0) {
-            cp_v = relay[0 * 64 + lane]; cp_t = relay[1 * 64 + lane];
-            dp[0] = relay[2 * 64 + lane]; dp[1] = relay[3 * 64 + lane];
-            dp[2] = relay[4 * 64 + lane]; dp[3] = relay[5 * 64 + lane];
-        }
-        // Branch-free chain body: the row kinds only steer selects, so the serial critical
-        // path is the reference's arithmetic (2 mul, 2 sub, 6 div per cell) and nothing else.
-        //   INTERIOR a = -q - vis, b = 3/dt + 2 vis, c = q - vis      (AdiSolver3D.cpp:760-762)
-        //   START    a = 0,  FREE: b = 2, c = -1 ; NOSLIP: b = 1, c = 0 (ApplyBC0, :804-827)
-        //   END      c = 0,  FREE: a = -1, b = 2 ; NOSLIP: a = 0, b = 1 (ApplyBC1, :829-852)
-        //   SKIP     identity row.  START and SKIP rows restart the recurrence: the carried
-        //   c', d' are zeroed first, which makes the general step equal to c0/b0, d0/b0 exactly.
-#pragma unroll
-        for (int t = 0; t < CH; t++) {
-            const int s = s0 + t;
-            const int code = (cpack[t >> 3] >> (4 * (t & 7))) & 0xF;
-            const int kind = code & 3;
-            const bool is_int = kind == ROW_INTERIOR;
-            const bool restart = kind == ROW_START || kind == ROW_SKIP;
-            const bool vfree = (code & ROW_VELFREE) != 0, tfree = (code & ROW_TEMPFREE) != 0;
-            const bool is_start = kind == ROW_START, is_end = kind == ROW_END;
-            const R q = st0[t];
-            const R a_v = is_int ? (-q - p.vis_v) : ((is_end && vfree) ? R(-1) : R(0));
-            const R c_v = is_int ? (q - p.vis_v) : ((is_start && vfree) ? R(-1) : R(0));
-            const R b_v = is_int ? p.b_v : (vfree ? R(2) : R(1));
-            const R a_t = is_int ? (-q - p.vis_t) : ((is_end && tfree) ? R(-1) : R(0));
-            const R c_t = is_int ? (q - p.vis_t) : ((is_start && tfree) ? R(-1) : R(0));
-            const R b_t = is_int ? p.b_t : (tfree ? R(2) : R(1));
-            const R dT = ldsD[(size_t)s * 64 + lane];
-            if (restart) { cp_v = R(0); cp_t = R(0); dp[0] = R(0); dp[1] = R(0); dp[2] = R(0); dp[3] = R(0); }
-            const R den_v = b_v - a_v * cp_v;                 // Algorithms.h:30-31
-            const R den_t = b_t - a_t * cp_t;
-            const R n0 = st1[t] - dp[0] * a_v;
-            const R n1 = st2[t] - dp[1] * a_v;
-            const R n2 = st3[t] - dp[2] * a_v;
-            const R n3 = dT - dp[3] * a_t;
-            cp_v = c_v / den_v; cp_t = c_t / den_t;
-            dp[0] = n0 / den_v; dp[1] = n1 / den_v; dp[2] = n2 / den_v; dp[3] = n3 / den_t;
-            st0[t] = cp_v; st1[t] = dp[0]; st2[t] = dp[1]; st3[t] = dp[2];
-            ldsD[(size_t)s * 64 + lane] = dp[3];
-            ldsC[(size_t)s * 64 + lane] = cp_t;
-            // stop the scheduler from hoisting every later cell's chain-independent work (coefficient
-            // selects, LDS reads) to the top of the relay turn: that only buys register spills
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        relay[0 * 64 + lane] = cp_v; relay[1 * 64 + lane] = cp_t;
-        relay[2 * 64 + lane] = dp[0]; relay[3 * 64 + lane] = dp[1];
-        relay[4 * 64 + lane] = dp[2]; relay[5 * 64 + lane] = dp[3];
+#define FWD_PASS(VAR, DREAD, DWRITE, CWRITE)                                                              \
+    {                                                                                                     \
+        R cp = R(0), dp = R(0);                                                                           \
+        if (w > 0) { cp = relay[(2 * VAR) * 64 + lane]; dp = relay[(2 * VAR + 1) * 64 + lane]; }          \
+        const R vis = VAR == 3 ? p.vis_t : p.vis_v, bb = VAR == 3 ? p.b_t : p.b_v;                        \
+        _Pragma("unroll") for (int t = 0; t < CH; t++) {                                                  \
+            const int code = (cpack[t >> 3] >> (4 * (t & 7))) & 0xF;                                      \
+            const int kind = code & 3;                                                                    \
+            const bool is_int = kind == ROW_INTERIOR, restart = kind == ROW_START || kind == ROW_SKIP;    \
+            const bool fr = (code & (VAR == 3 ? ROW_TEMPFREE : ROW_VELFREE)) != 0;                        \
+            const R q = st0[t];                                                                           \
+            const R a = is_int ? (-q - vis) : ((kind == ROW_END && fr) ? R(-1) : R(0));                   \
+            const R c = is_int ? (q - vis) : ((kind == ROW_START && fr) ? R(-1) : R(0));                  \
+            const R b = is_int ? bb : (fr ? R(2) : R(1));                                                 \
+            const R d = DREAD;                                                                            \
+            if (restart) { cp = R(0); dp = R(0); }                                                        \
+            const R den = b - a * cp;                                                                     \
+            const R num = d - dp * a;                                                                     \
+            cp = c / den;                                                                                 \
+            dp = num / den;                                                                               \
+            DWRITE;                                                                                       \
+            CWRITE;                                                                                       \
+            if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);                                          \
+        }                                                                                                 \
+        relay[(2 * VAR) * 64 + lane] = cp; relay[(2 * VAR + 1) * 64 + lane] = dp;                         \
     }
+    FWD_PASS(3, myD[t * 64], myD[t * 64] = dp, myC[t * 64] = cp)
+    __syncthreads();
+    FWD_PASS(0, st1[t], st1[t] = dp, (void)0)
+    __syncthreads();
+    FWD_PASS(1, st2[t], st2[t] = dp, (void)0)
+    __syncthreads();
+    FWD_PASS(2, st3[t], st3[t] = dp, st0[t] = cp)          // last pass over the cell: c'_uvw replaces q
+#undef FWD_PASS
     STAMP(3);
-    for (int i = w; i < PIPE_NW; i++) __syncthreads();
+    for (int i = w + 3; i < PIPE_NW + 3; i++) __syncthreads();
 
     // ------------------------------------------------------------------ B: backward relay (registers/LDS only)
     for (int i = 0; i < PIPE_NW - 1 - w; i++) __syncthreads();
@@ -476,8 +467,8 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
         for (int t = CH - 1; t >= 0; t--) {
             const int s = s0 + t;
             const int kind = (cpack[t >> 3] >> (4 * (t & 7))) & 3;
-            const R c_v = st0[t], c_t = ldsC[(size_t)s * 64 + lane];
-            const R e0 = st1[t], e1 = st2[t], e2 = st3[t], e3 = ldsD[(size_t)s * 64 + lane];
+            const R c_v = st0[t], c_t = myC[t * 64];
+            const R e0 = st1[t], e1 = st2[t], e2 = st3[t], e3 = myD[t * 64];
             // x[num-1] = d[num-1] (Algorithms.h:34): END and SKIP rows do not look at x[i+1]
             if (kind == ROW_END || kind == ROW_SKIP) { x[0] = R(0); x[1] = R(0); x[2] = R(0); x[3] = R(0); }
             x[0] = e0 - c_v * x[0]; x[1] = e1 - c_v * x[1];   // Algorithms.h:36-37
@@ -497,22 +488,24 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
     {
         // does every valid cell of the chunk sit on a segment?  (then whole tiles can be stored)
         const int len = n - s0 < 0 ? 0 : (n - s0 > CH ? CH : n - s0);
-        const unsigned long long chunk_mask = len >= 64 ? ~0ull : ((1ull << len) - 1ull);
+        const unsigned chunk_mask = len >= 32 ? 0xFFFFFFFFu : ((1u << len) - 1u);
         const bool all_seg = __all((!lane_valid) || ((segmask & chunk_mask) == chunk_mask));
 #pragma unroll
         for (int pass = 0; pass < CK::NPASS; pass++) {
             const int c0 = pass * PC;
-            const unsigned seg_p = (unsigned)(segmask >> c0), in_p = (unsigned)(inmask >> c0);
+            const unsigned seg_p = segmask >> c0, in_p = inmask >> c0;
+            typename CK::Keep keepN, keepT;
 #pragma unroll
             for (int v = 0; v < 4; v++) {
                 R xv[PC];
 #pragma unroll
                 for (int t = 0; t < PC; t++) xv[t] = v == 0 ? st1[c0 + t] : (v == 1 ? st2[c0 + t] : (v == 2 ? st3[c0 + t] : st0[c0 + t]));
                 const rsrc_t rNext = ck.field(p.next(v), p.plane);
-                ck.store(rNext, c0, xv, seg_p, all_seg);
+                ck.store(rNext, c0, xv, seg_p, all_seg, keepN);
                 if (p.merge) {
                     R tv[PC];
                     ck.load(ck.field(p.temp(v), p.plane), 0, c0, tv);
+                    CK::pin(keepN); CK::pin(keepT);      // the load returned: every older store has fetched its data
                     if (((in_p & ~seg_p) & (PC >= 32 ? 0xFFFFFFFFu : ((1u << PC) - 1u))) != 0) {
                         // NODE_IN cell outside every segment (run without a closing cell,
                         // Grid3D.cpp:87-117): the reference merges the stale `next` value
@@ -527,7 +520,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
                             if (p.merge == 2) tv[t] = (tv[t] + xv[t]) / R(2);
                         }
                     }
-                    ck.store(ck.field(p.temp_out(v), p.plane), c0, tv, 0xFFFFFFFFu, true);
+                    ck.store(ck.field(p.temp_out(v), p.plane), c0, tv, 0xFFFFFFFFu, true, keepT);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -545,7 +538,7 @@ static bool launch_one(fs3d_ctx *c, const SweepParams<R> &p)
     const int n_tiles = (la_len + 63) / 64;
     const size_t tile = Chunk<R, DIR, CH>::TILE_ELEMS;
     const size_t lds_c = (size_t)PIPE_NW * CH * 64 + (tile <= (size_t)CH * 64 ? 0 : (size_t)PIPE_NW * tile);
-    const size_t lds = ((size_t)PIPE_NW * CH * 64 + lds_c + 6 * 64) * sizeof(R);
+    const size_t lds = ((size_t)PIPE_NW * CH * 64 + lds_c + 8 * 64) * sizeof(R);
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void *)k_sweep_pipe<R, DIR, CH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
