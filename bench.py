@@ -174,6 +174,14 @@ def main():
         local_cells = (x1 - x0) * n * n
         alg_bytes = 16 * esize * local_cells          # 16 words/cell/sweep (cur4+temp4 in, next4+temp4 out)
         achieved = alg_bytes / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
+        # HBM bytes per launch of the dominant kernel from the PMC passes (collected separately, profiles/)
+        traffic = None
+        try:
+            pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            if pt.get("grid") == [n, n, n] and pt.get("dtype") == args.dtype and world == 1:
+                traffic = pt.get(names[k])
+        except Exception:
+            traffic = None
         out = {
             "metric": "Mcells/sec (FluidSolver3D step)", "value": round(cells * args.steps / sec / 1e6, 2),
             "unit": "Mcells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -185,7 +193,7 @@ def main():
                        "grid": [n, n, n], "parallelism": "x-slab x%d" % world, "sweep_kernel": args.kernel,
                        "final_div_error": err},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": names[k], "avg_launch_ms": round(per_launch_ms, 4),
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "per_class_ms_per_launch": {nm: round(ms_cls[j] / max(1, n_cls[j]), 4)

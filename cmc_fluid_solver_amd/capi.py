@@ -43,6 +43,9 @@ SYMBOLS = {
     "fs3d_get_layer": (_i, [_vp, _vp, _vp, _i, _i, _i]),
     "fs3d_comm_unique_id": (_i, [_vp]),
     "fs3d_comm_init": (_i, [_vp, _vp, _i, _i]),
+    "fs3d_local_group_create": (_i, [_i, C.POINTER(_vp)]),
+    "fs3d_local_group_destroy": (None, [_vp]),
+    "fs3d_comm_init_local": (_i, [_vp, _vp, _i]),
     "fs3d_last_step_timing": (_i, [_vp, C.POINTER(C.c_float), C.POINTER(_i)]),
     "fs3d_enable_timing": (_i, [_vp, _i]),
     "fs3d_profile_sweep": (_i, [_vp, _i, _d, _i, _i, _i, C.POINTER(C.c_ulonglong), _i, C.POINTER(_i)]),
@@ -130,6 +133,10 @@ class Solver:
         buf = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
         self._chk(self.lib.fs3d_comm_init(self.h, buf, rank, nranks))
 
+    def comm_init_local(self, group, rank):
+        self._chk(self.lib.fs3d_comm_init_local(self.h, group.h, rank))
+        self._group = group        # keep the group alive as long as the context
+
     # -- reference-shaped interface -----------------------------------------------
     def UpdateBoundaries(self):
         self._chk(self.lib.fs3d_update_boundaries(self.h))
@@ -191,6 +198,58 @@ class Solver:
         ms, n = (C.c_float * 4)(), (C.c_int * 4)()
         self._chk(self.lib.fs3d_last_step_timing(self.h, ms, n))
         return list(ms), list(n)
+
+
+class LocalGroup:
+    """In-process slab group (fs3d_local_group_create): one Solver per slab, each driven by its own
+    thread.  `run(fn)` calls fn(rank, solver) on every slab concurrently and returns the results."""
+
+    def __init__(self, nodes, params, nranks, dtype=np.float32, devices=None):
+        from .slab import slab_range
+        self.lib = load()
+        self.h = C.c_void_p()
+        st = self.lib.fs3d_local_group_create(nranks, C.byref(self.h))
+        if st != OK:
+            raise Fs3dError(st, "fs3d_local_group_create")
+        self.solvers = []
+        for r in range(nranks):
+            s = Solver(nodes, params, dtype=dtype, device=(devices[r] if devices else 0),
+                       x_range=slab_range(nodes.dimx, r, nranks))
+            s.comm_init_local(self, r)
+            self.solvers.append(s)
+
+    def run(self, fn):
+        import threading
+        out, exc = [None] * len(self.solvers), [None] * len(self.solvers)
+
+        def work(r):
+            try:
+                out[r] = fn(r, self.solvers[r])
+            except BaseException as e:      # noqa: BLE001 - re-raised below
+                exc[r] = e
+        th = [threading.Thread(target=work, args=(r,)) for r in range(len(self.solvers))]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        for e in exc:
+            if e is not None:
+                raise e
+        return out
+
+    def close(self):
+        for s in self.solvers:
+            s.close()
+        self.solvers = []
+        if self.h:
+            self.lib.fs3d_local_group_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def fluid_params(dtype, Re, Pr, lam):

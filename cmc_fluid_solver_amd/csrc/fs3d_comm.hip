@@ -1,8 +1,133 @@
-// RCCL halo exchange / all-reduce for the x-slab decomposition (one process per GPU).
+// Halo / carry exchange and the error all-reduce of the x-slab decomposition.
+// Two transports behind the same four calls:
+//   * RCCL (one process per GPU, fs3d_comm_init)            -- the production path, stream-ordered p2p groups;
+//   * in-process (one host thread per slab context, fs3d_comm_init_local) -- device-to-device copies with a
+//     host rendezvous; the reference's own single-process multi-GPU mode (Common/GPUplan.h:29-108) and the
+//     way the slab protocol is exercised on a single card.
 #include "fs3d_comm.h"
 #include <rccl/rccl.h>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
+#include <deque>
+#include <mutex>
+#include <vector>
+
+struct XOp { void *ptr; size_t count; int peer; bool send; };
+
+// ---- in-process transport -------------------------------------------------------------------------------
+struct LocalMsg { const void *ptr; size_t bytes; };
+struct fs3d_local_group {
+    int n;
+    std::mutex m;
+    std::condition_variable cv;
+    std::vector<std::deque<LocalMsg>> box;      // [src * n + dst]
+    std::vector<long long> posted, done;        // [src * n + dst]
+    std::vector<double> red;                    // [rank][2]
+    double sum[2][2];
+    int arrived = 0;
+    long long gen = 0;
+    bool broken = false;
+    explicit fs3d_local_group(int n_) : n(n_), box((size_t)n_ * n_), posted((size_t)n_ * n_, 0), done((size_t)n_ * n_, 0), red((size_t)n_ * 2, 0.0) {}
+};
+
+extern "C" fs3d_status fs3d_local_group_create(int nranks, void **group_out)
+{
+    if (!group_out || nranks < 1 || nranks > 64) return FS3D_ERR_INVALID;
+    *group_out = new fs3d_local_group(nranks);
+    return FS3D_OK;
+}
+
+extern "C" void fs3d_local_group_destroy(void *group) { delete (fs3d_local_group *)group; }
+
+extern "C" fs3d_status fs3d_comm_init_local(fs3d_ctx *c, void *group, int rank)
+{
+    fs3d_local_group *g = (fs3d_local_group *)group;
+    if (!c || !g || rank < 0 || rank >= g->n || c->comm) return FS3D_ERR_INVALID;
+    c->local = g; c->rank = rank; c->nranks = g->n;
+    if (const char *e = getenv("FS3D_XBLOCKS")) { int v = atoi(e); if (v >= 1 && v <= 64) c->xblocks = v; }
+    return FS3D_OK;
+}
+
+static fs3d_status local_fail(fs3d_ctx *c, const char *what)
+{
+    fs3d_local_group *g = (fs3d_local_group *)c->local;
+    { std::lock_guard<std::mutex> lk(g->m); g->broken = true; }
+    g->cv.notify_all();
+    c->err = std::string("in-process transport: ") + what;
+    return FS3D_ERR_COMM;
+}
+
+static fs3d_status local_exec(fs3d_ctx *c, const std::vector<XOp> &ops)
+{
+    fs3d_local_group *g = (fs3d_local_group *)c->local;
+    const int n = g->n, me = c->rank;
+    if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return local_fail(c, "stream sync before send");
+    {
+        std::lock_guard<std::mutex> lk(g->m);
+        for (const XOp &o : ops) if (o.send) { g->box[(size_t)me * n + o.peer].push_back({o.ptr, o.count * c->esize}); g->posted[(size_t)me * n + o.peer]++; }
+    }
+    g->cv.notify_all();
+    std::vector<int> took(n, 0);
+    for (const XOp &o : ops) {
+        if (o.send) continue;
+        LocalMsg msg;
+        {
+            std::unique_lock<std::mutex> lk(g->m);
+            auto &q = g->box[(size_t)o.peer * n + me];
+            g->cv.wait(lk, [&] { return !q.empty() || g->broken; });
+            if (g->broken) { c->err = "in-process transport: a peer failed"; return FS3D_ERR_COMM; }
+            msg = q.front(); q.pop_front();
+        }
+        if (msg.bytes != o.count * c->esize) return local_fail(c, "send/recv size mismatch");
+        if (hipMemcpyAsync(o.ptr, msg.ptr, msg.bytes, hipMemcpyDefault, c->stream) != hipSuccess) return local_fail(c, "device copy");
+        took[o.peer]++;
+    }
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return local_fail(c, "stream sync after recv");
+    {
+        std::unique_lock<std::mutex> lk(g->m);
+        for (int p = 0; p < n; p++) g->done[(size_t)p * n + me] += took[p];
+        g->cv.notify_all();
+        // the source buffers stay untouched until every peer has copied them
+        g->cv.wait(lk, [&] {
+            if (g->broken) return true;
+            for (int p = 0; p < n; p++) if (g->done[(size_t)me * n + p] < g->posted[(size_t)me * n + p]) return false;
+            return true;
+        });
+        if (g->broken) { c->err = "in-process transport: a peer failed"; return FS3D_ERR_COMM; }
+    }
+    return FS3D_OK;
+}
+
+static fs3d_status local_allreduce_sum2(fs3d_ctx *c, double *dev2)
+{
+    fs3d_local_group *g = (fs3d_local_group *)c->local;
+    double v[2];
+    if (hipSetDevice(c->device) != hipSuccess || hipMemcpyAsync(v, dev2, sizeof v, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess) return local_fail(c, "all-reduce read");
+    {
+        std::unique_lock<std::mutex> lk(g->m);
+        g->red[2 * c->rank] = v[0]; g->red[2 * c->rank + 1] = v[1];
+        const long long my_gen = g->gen;
+        if (++g->arrived == g->n) {
+            double s0 = 0, s1 = 0;
+            for (int r = 0; r < g->n; r++) { s0 += g->red[2 * r]; s1 += g->red[2 * r + 1]; }   // rank order
+            g->sum[my_gen & 1][0] = s0; g->sum[my_gen & 1][1] = s1;
+            g->arrived = 0; g->gen++;
+            g->cv.notify_all();
+        } else {
+            g->cv.wait(lk, [&] { return g->gen != my_gen || g->broken; });
+            if (g->broken) { c->err = "in-process transport: a peer failed"; return FS3D_ERR_COMM; }
+        }
+        v[0] = g->sum[my_gen & 1][0]; v[1] = g->sum[my_gen & 1][1];
+    }
+    if (hipMemcpyAsync(dev2, v, sizeof v, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess) return local_fail(c, "all-reduce write");
+    return FS3D_OK;
+}
+
+// ---- RCCL transport -------------------------------------------------------------------------------------
 
 static fs3d_status cfail(fs3d_ctx *c, const char *what, ncclResult_t r)
 {
@@ -34,57 +159,63 @@ extern "C" fs3d_status fs3d_comm_init(fs3d_ctx *c, const void *unique_id_128, in
     ncclComm_t comm;
     NCCLCHK(c, ncclCommInitRank(&comm, nranks, id, rank));
     c->comm = comm; c->rank = rank; c->nranks = nranks;
+    if (const char *e = getenv("FS3D_XBLOCKS")) { int v = atoi(e); if (v >= 1 && v <= 64) c->xblocks = v; }
     return FS3D_OK;
 }
 
 void fs3d_comm_destroy(fs3d_ctx *c)
 {
     if (c && c->comm) { ncclCommDestroy((ncclComm_t)c->comm); c->comm = nullptr; }
+    if (c) c->local = nullptr;
     if (c) for (int i = 0; i < 4; i++) if (c->carry[i]) { hipFree(c->carry[i]); c->carry[i] = nullptr; }
+}
+
+// one grouped exchange: every send and receive of `ops` is in flight together (no ordering deadlock)
+static fs3d_status exec_group(fs3d_ctx *c, const std::vector<XOp> &ops)
+{
+    if (c->local) return local_exec(c, ops);
+    if (!c->comm) { c->err = "slab context has no communicator (fs3d_comm_init / fs3d_comm_init_local)"; return FS3D_ERR_COMM; }
+    const ncclDataType_t dt = c->prec == FS3D_F32 ? ncclFloat : ncclDouble;
+    NCCLCHK(c, ncclGroupStart());
+    for (const XOp &o : ops) {
+        if (o.send) NCCLCHK(c, ncclSend(o.ptr, o.count, dt, o.peer, (ncclComm_t)c->comm, c->stream));
+        else NCCLCHK(c, ncclRecv(o.ptr, o.count, dt, o.peer, (ncclComm_t)c->comm, c->stream));
+    }
+    NCCLCHK(c, ncclGroupEnd());
+    return FS3D_OK;
 }
 
 fs3d_status fs3d_comm_halo_exchange(fs3d_ctx *c, int buf, int nfields)
 {
     if (c->nranks == 1) return FS3D_OK;
-    ncclComm_t comm = (ncclComm_t)c->comm;
-    const ncclDataType_t dt = c->prec == FS3D_F32 ? ncclFloat : ncclDouble;
     const size_t pl = (size_t)c->plane;
     // layout per field: [ghost lo][dimx owned planes][ghost hi]; one grouped send/recv per neighbour
-    NCCLCHK(c, ncclGroupStart());
+    std::vector<XOp> ops;
     for (int v = 0; v < nfields; v++) {
         char *base = (char *)c->lay[buf] + (size_t)v * c->fstride * c->esize;
         char *first = base + pl * c->esize;                       // first owned plane
         char *last = base + (size_t)c->dimx * pl * c->esize;      // last owned plane
         char *glo = base;                                         // ghost below
         char *ghi = base + (size_t)(c->dimx + 1) * pl * c->esize; // ghost above
-        if (c->rank > 0) {
-            NCCLCHK(c, ncclSend(first, pl, dt, c->rank - 1, comm, c->stream));
-            NCCLCHK(c, ncclRecv(glo, pl, dt, c->rank - 1, comm, c->stream));
-        }
-        if (c->rank < c->nranks - 1) {
-            NCCLCHK(c, ncclSend(last, pl, dt, c->rank + 1, comm, c->stream));
-            NCCLCHK(c, ncclRecv(ghi, pl, dt, c->rank + 1, comm, c->stream));
-        }
+        if (c->rank > 0) { ops.push_back({first, pl, c->rank - 1, true}); ops.push_back({glo, pl, c->rank - 1, false}); }
+        if (c->rank < c->nranks - 1) { ops.push_back({last, pl, c->rank + 1, true}); ops.push_back({ghi, pl, c->rank + 1, false}); }
     }
-    NCCLCHK(c, ncclGroupEnd());
-    return FS3D_OK;
+    return exec_group(c, ops);
 }
 
 fs3d_status fs3d_comm_allreduce_sum2(fs3d_ctx *c, double *dev2)
 {
     if (c->nranks == 1) return FS3D_OK;
+    if (c->local) return local_allreduce_sum2(c, dev2);
+    if (!c->comm) { c->err = "slab context has no communicator"; return FS3D_ERR_COMM; }
     NCCLCHK(c, ncclAllReduce(dev2, dev2, 2, ncclDouble, ncclSum, (ncclComm_t)c->comm, c->stream));
     return FS3D_OK;
 }
 
-fs3d_status fs3d_comm_send(fs3d_ctx *c, const void *dev, size_t count, int peer)
+fs3d_status fs3d_comm_xfer_rows(fs3d_ctx *c, void *dev, int nrows, size_t pitch, long long l0, long long l1, int peer, bool send)
 {
-    NCCLCHK(c, ncclSend(dev, count, c->prec == FS3D_F32 ? ncclFloat : ncclDouble, peer, (ncclComm_t)c->comm, c->stream));
-    return FS3D_OK;
-}
-
-fs3d_status fs3d_comm_recv(fs3d_ctx *c, void *dev, size_t count, int peer)
-{
-    NCCLCHK(c, ncclRecv(dev, count, c->prec == FS3D_F32 ? ncclFloat : ncclDouble, peer, (ncclComm_t)c->comm, c->stream));
-    return FS3D_OK;
+    std::vector<XOp> ops;
+    for (int r = 0; r < nrows; r++)
+        ops.push_back({(char *)dev + ((size_t)r * pitch + (size_t)l0) * c->esize, (size_t)(l1 - l0), peer, send});
+    return exec_group(c, ops);
 }

@@ -95,13 +95,15 @@ struct fs3d_ctx {
     int stamps_cap = 0;
     // comm
     void *comm = nullptr;          // ncclComm_t
+    void *local = nullptr;         // fs3d_local_group* (in-process transport)
     void *carry[4] = {};           // cross-slab X sweep: fwd in/out (6 x plane), bwd in/out (4 x plane)
     int rank = 0, nranks = 1;
+    int xblocks = 4;               // line blocks of the cross-slab X sweep pipeline (env FS3D_XBLOCKS)
     std::string err;
 };
 
 // kernels_*.hip
 template <typename R> void launch_sweep_line(fs3d_ctx *c, int dir, const SweepParams<R> &p);
 template <typename R> bool launch_sweep_pipe(fs3d_ctx *c, int dir, const SweepParams<R> &p); // false: dims unsupported
-template <typename R> void launch_xsweep_fwd(fs3d_ctx *c, const SweepParams<R> &p, const void *carry_in, void *carry_out);
-template <typename R> void launch_xsweep_bwd(fs3d_ctx *c, const SweepParams<R> &p, const void *xcarry_in, void *xcarry_out);
+template <typename R> void launch_xsweep_fwd(fs3d_ctx *c, const SweepParams<R> &p, const void *carry_in, void *carry_out, long long l0, long long l1);
+template <typename R> void launch_xsweep_bwd(fs3d_ctx *c, const SweepParams<R> &p, const void *xcarry_in, void *xcarry_out, long long l0, long long l1);

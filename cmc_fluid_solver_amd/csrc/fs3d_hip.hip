@@ -501,6 +501,9 @@ static fs3d_status ensure_scratch(fs3d_ctx *c)
 }
 
 // Cross-slab X sweep (nranks > 1): forward over the slabs 0 -> R-1, backward R-1 -> 0, carries over RCCL.
+// The lines of the plane are cut into `xblocks` blocks that travel through the ranks as a pipeline (rank r
+// works on block b while rank r+1 works on block b-1) -- the reference's `blocking` idea (AdiSolver3D.cu:642-881).
+// Carries are [value][line]; a block moves as one grouped transfer of its 6 (forward) / 4 (backward) row pieces.
 template <typename R>
 static fs3d_status xsweep_multi(fs3d_ctx *c, SweepParams<R> &p)
 {
@@ -513,12 +516,25 @@ static fs3d_status xsweep_multi(fs3d_ctx *c, SweepParams<R> &p)
         HIPCHK(c, hipMalloc(&c->carry[2], 4 * pl * c->esize)); HIPCHK(c, hipMalloc(&c->carry[3], 4 * pl * c->esize));
     }
     const bool first = c->rank == 0, last = c->rank == c->nranks - 1;
-    if (!first && (st = fs3d_comm_recv(c, c->carry[0], 6 * pl, c->rank - 1))) return st;
-    launch_xsweep_fwd<R>(c, p, first ? nullptr : c->carry[0], c->carry[1]);
-    if (!last && (st = fs3d_comm_send(c, c->carry[1], 6 * pl, c->rank + 1))) return st;
-    if (!last && (st = fs3d_comm_recv(c, c->carry[2], 4 * pl, c->rank + 1))) return st;
-    launch_xsweep_bwd<R>(c, p, last ? nullptr : c->carry[2], c->carry[3]);
-    if (!first && (st = fs3d_comm_send(c, c->carry[3], 4 * pl, c->rank - 1))) return st;
+    const int nb = c->xblocks < 1 ? 1 : c->xblocks;
+    auto range = [&](int b, long long &l0, long long &l1) {
+        const long long per = ((long long)pl / 64 + nb - 1) / nb * 64;      // whole waves per block
+        l0 = std::min<long long>((long long)b * per, (long long)pl); l1 = std::min<long long>(l0 + per, (long long)pl);
+    };
+    for (int b = 0; b < nb; b++) {
+        long long l0, l1; range(b, l0, l1);
+        if (l1 <= l0) continue;
+        if (!first && (st = fs3d_comm_xfer_rows(c, c->carry[0], 6, pl, l0, l1, c->rank - 1, false))) return st;
+        launch_xsweep_fwd<R>(c, p, first ? nullptr : c->carry[0], c->carry[1], l0, l1);
+        if (!last && (st = fs3d_comm_xfer_rows(c, c->carry[1], 6, pl, l0, l1, c->rank + 1, true))) return st;
+    }
+    for (int b = 0; b < nb; b++) {
+        long long l0, l1; range(b, l0, l1);
+        if (l1 <= l0) continue;
+        if (!last && (st = fs3d_comm_xfer_rows(c, c->carry[2], 4, pl, l0, l1, c->rank + 1, false))) return st;
+        launch_xsweep_bwd<R>(c, p, last ? nullptr : c->carry[2], c->carry[3], l0, l1);
+        if (!first && (st = fs3d_comm_xfer_rows(c, c->carry[3], 4, pl, l0, l1, c->rank - 1, true))) return st;
+    }
     return FS3D_OK;
 }
 

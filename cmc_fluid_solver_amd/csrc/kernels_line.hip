@@ -94,13 +94,13 @@ template void launch_sweep_line<double>(fs3d_ctx *, int, const SweepParams<doubl
 // the x of the neighbour's first plane (xcarry_in, 4 values per line; none on the last rank).
 // This is the reference's pipelined Thomas (AdiSolver3D.cu:524-640) with CPU-ordering semantics;
 // cell for cell it performs the single-GPU arithmetic, so slabbed results are bit-identical.
-// Carry layout: [value][line], line = j*dimz + k.
+// Carry layout: [value][line], line = j*dimz + k (the caller packs/sends the [l0,l1) part of each value row).
 template <typename R>
-__global__ void __launch_bounds__(256) k_xsweep_fwd(SweepParams<R> p, const R *carry_in, R *carry_out)
+__global__ void __launch_bounds__(256) k_xsweep_fwd(SweepParams<R> p, const R *carry_in, R *carry_out, long long l0, long long l1)
 {
-    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long tid = l0 + (long long)blockIdx.x * blockDim.x + threadIdx.x;   // lines [l0, l1) of the plane
     const long long nlines = p.plane;
-    if (tid >= nlines) return;
+    if (tid >= l1) return;
     R cp_v = R(0), cp_t = R(0), dp[4] = {R(0), R(0), R(0), R(0)};
     if (carry_in) {
         cp_v = carry_in[0 * nlines + tid]; cp_t = carry_in[1 * nlines + tid];
@@ -124,11 +124,11 @@ __global__ void __launch_bounds__(256) k_xsweep_fwd(SweepParams<R> p, const R *c
 }
 
 template <typename R>
-__global__ void __launch_bounds__(256) k_xsweep_bwd(SweepParams<R> p, const R *xcarry_in, R *xcarry_out)
+__global__ void __launch_bounds__(256) k_xsweep_bwd(SweepParams<R> p, const R *xcarry_in, R *xcarry_out, long long l0, long long l1)
 {
-    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long tid = l0 + (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long nlines = p.plane;
-    if (tid >= nlines) return;
+    if (tid >= l1) return;
     R x[4] = {R(0), R(0), R(0), R(0)};
     if (xcarry_in) { x[0] = xcarry_in[tid]; x[1] = xcarry_in[nlines + tid]; x[2] = xcarry_in[2 * nlines + tid]; x[3] = xcarry_in[3 * nlines + tid]; }
     for (int s = p.dimx - 1; s >= 0; s--) {
@@ -163,18 +163,18 @@ __global__ void __launch_bounds__(256) k_xsweep_bwd(SweepParams<R> p, const R *x
 }
 
 template <typename R>
-void launch_xsweep_fwd(fs3d_ctx *c, const SweepParams<R> &p, const void *carry_in, void *carry_out)
+void launch_xsweep_fwd(fs3d_ctx *c, const SweepParams<R> &p, const void *carry_in, void *carry_out, long long l0, long long l1)
 {
-    const unsigned grid = (unsigned)((p.plane + 63) / 64);
-    hipLaunchKernelGGL((k_xsweep_fwd<R>), dim3(grid), dim3(64), 0, c->stream, p, (const R *)carry_in, (R *)carry_out);
+    const unsigned grid = (unsigned)((l1 - l0 + 63) / 64);
+    hipLaunchKernelGGL((k_xsweep_fwd<R>), dim3(grid), dim3(64), 0, c->stream, p, (const R *)carry_in, (R *)carry_out, l0, l1);
 }
 template <typename R>
-void launch_xsweep_bwd(fs3d_ctx *c, const SweepParams<R> &p, const void *xcarry_in, void *xcarry_out)
+void launch_xsweep_bwd(fs3d_ctx *c, const SweepParams<R> &p, const void *xcarry_in, void *xcarry_out, long long l0, long long l1)
 {
-    const unsigned grid = (unsigned)((p.plane + 63) / 64);
-    hipLaunchKernelGGL((k_xsweep_bwd<R>), dim3(grid), dim3(64), 0, c->stream, p, (const R *)xcarry_in, (R *)xcarry_out);
+    const unsigned grid = (unsigned)((l1 - l0 + 63) / 64);
+    hipLaunchKernelGGL((k_xsweep_bwd<R>), dim3(grid), dim3(64), 0, c->stream, p, (const R *)xcarry_in, (R *)xcarry_out, l0, l1);
 }
-template void launch_xsweep_fwd<float>(fs3d_ctx *, const SweepParams<float> &, const void *, void *);
-template void launch_xsweep_fwd<double>(fs3d_ctx *, const SweepParams<double> &, const void *, void *);
-template void launch_xsweep_bwd<float>(fs3d_ctx *, const SweepParams<float> &, const void *, void *);
-template void launch_xsweep_bwd<double>(fs3d_ctx *, const SweepParams<double> &, const void *, void *);
+template void launch_xsweep_fwd<float>(fs3d_ctx *, const SweepParams<float> &, const void *, void *, long long, long long);
+template void launch_xsweep_fwd<double>(fs3d_ctx *, const SweepParams<double> &, const void *, void *, long long, long long);
+template void launch_xsweep_bwd<float>(fs3d_ctx *, const SweepParams<float> &, const void *, void *, long long, long long);
+template void launch_xsweep_bwd<double>(fs3d_ctx *, const SweepParams<double> &, const void *, void *, long long, long long);

@@ -157,6 +157,16 @@ fs3d_status fs3d_get_layer(fs3d_ctx *ctx, void *outV, double *outT,
 fs3d_status fs3d_comm_unique_id(void *unique_id_128);
 fs3d_status fs3d_comm_init(fs3d_ctx *ctx, const void *unique_id_128, int rank, int nranks);
 
+/* The reference's other multi-GPU mode: ONE process driving several GPUs (GPUplan, Common/GPUplan.h:29-108,
+ * `multiDev*` helpers).  Here: one slab context per GPU, each driven by its own host thread, joined by an
+ * in-process group -- halos and carries move as device-to-device copies with a host rendezvous instead of
+ * RCCL.  Every collective call (time_step, sweep, eval_div_error ...) must then be made by all the
+ * group's threads concurrently, as with RCCL ranks.  Contexts may share a device (used to exercise the
+ * slab protocol on a single card).  Destroy the contexts before the group. */
+fs3d_status fs3d_local_group_create(int nranks, void **group_out);
+void fs3d_local_group_destroy(void *group);
+fs3d_status fs3d_comm_init_local(fs3d_ctx *ctx, void *group, int rank);
+
 /* ---- measurement ---------------------------------------------------------------
  * Wall time of the kernels of the last fs3d_time_step* call, measured with HIP events
  * on the context's stream: ms[0]=Z sweeps, [1]=Y sweeps, [2]=X sweeps, [3]=everything

@@ -1,0 +1,114 @@
+"""The x-slab (multi-GPU) path on ONE card: several slab contexts joined by the in-process transport
+(fs3d_comm_init_local), one host thread per slab.  Everything but the wire is the code the RCCL ranks
+run -- halo planes, ghost-aware sweeps, the cross-slab X sweep with its line-block pipeline, the
+two-scalar reduction -- so the decomposed result must equal the single-context result value for value,
+and the oracle's.  (AdiSolver3D.cu:524-640 and TimeLayer3D.h:272-335 are the reference's versions.)
+"""
+import numpy as np
+import pytest
+
+from cmc_fluid_solver_amd import capi, grids
+from cmc_fluid_solver_amd.slab import slab_range
+
+pytestmark = pytest.mark.gpu
+
+DT = 0.1
+PARAMS = (200.0, 0.72, 1.4)
+
+
+def _single(g, dtype, steps, G, L):
+    s = capi.Solver(g, capi.fluid_params(dtype, *PARAMS), dtype)
+    s.UpdateBoundaries()
+    errs = [s.TimeStep(DT, G, L, True) for _ in range(steps)]
+    out = s.download_layer(capi.LAYER_CUR)
+    s.close()
+    return out, errs
+
+
+def _slabs(g, dtype, nranks, steps, G, L, xblocks=None, monkeypatch=None):
+    if xblocks is not None:
+        monkeypatch.setenv("FS3D_XBLOCKS", str(xblocks))
+    grp = capi.LocalGroup(g, capi.fluid_params(dtype, *PARAMS), nranks, dtype)
+
+    def work(rank, s):
+        s.UpdateBoundaries()
+        errs = [s.TimeStep(DT, G, L, True) for _ in range(steps)]
+        return s.download_layer(capi.LAYER_CUR), errs
+    res = grp.run(work)
+    grp.close()
+    fields = [np.concatenate([res[r][0][v] for r in range(nranks)], axis=0) for v in range(4)]
+    return fields, [res[r][1] for r in range(nranks)]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("nranks", [2, 3, 4])
+def test_slabs_equal_single_context(dtype, nranks):
+    g = grids.box_with_obstacle(30, 24, 32, h=0.03)          # 30 planes: uneven slabs for 4 ranks
+    ref, ref_err = _single(g, dtype, 3, 2, 2)
+    got, errs = _slabs(g, dtype, nranks, 3, 2, 2)
+    for v in range(4):
+        assert np.array_equal(ref[v], got[v]), "field %d differs between %d slabs and one context" % (v, nranks)
+    for r in range(nranks):                                   # every rank holds the global error
+        np.testing.assert_allclose(errs[r], ref_err, rtol=1e-12)
+
+
+@pytest.mark.parametrize("xblocks", [1, 3, 8])
+def test_x_pipeline_block_count_is_invisible(xblocks, monkeypatch):
+    g = grids.box_with_obstacle(24, 40, 48, h=0.03)          # plane = 1920 lines = 30 waves
+    ref, _ = _single(g, np.float32, 2, 1, 2)
+    got, _ = _slabs(g, np.float32, 3, 2, 1, 2, xblocks=xblocks, monkeypatch=monkeypatch)
+    for v in range(4):
+        assert np.array_equal(ref[v], got[v])
+
+
+def test_slabs_against_oracle():
+    from oracle import oracle as O
+    dtype = np.float32
+    g = grids.box(26, 20, 24, h=0.04)
+    params = capi.fluid_params(dtype, *PARAMS)
+    o = O.Oracle(g, params, dtype)
+    o.update_boundaries()
+    oerr = [o.time_step(DT, 2, 1)[1] for _ in range(2)]
+    got, errs = _slabs(g, dtype, 2, 2, 2, 1)
+    for v, b in enumerate(o.get_layer_fields(O.L_CUR)):
+        assert np.array_equal(got[v], b)
+    np.testing.assert_allclose(errs[0], oerr, rtol=1e-12)
+
+
+def test_slab_kernel_level_calls():
+    """fs3d_sweep / fs3d_eval_div_error are collective too (halo exchange inside)."""
+    dtype = np.float32
+    g = grids.box_with_obstacle(28, 24, 32, h=0.03)
+    base = [np.ascontiguousarray(a, dtype) for a in (g.vx, g.vy, g.vz, g.T)]
+    cur = grids.perturb(base, seed=7)
+    tmp = grids.perturb(base, seed=8)
+    s = capi.Solver(g, capi.fluid_params(dtype, *PARAMS), dtype)
+    s.upload_layer(capi.LAYER_CUR, cur); s.upload_layer(capi.LAYER_TEMP, tmp)
+    ref = {}
+    for d in (capi.DIR_X, capi.DIR_Y, capi.DIR_Z):
+        s.sweep(d, DT, capi.LAYER_CUR, capi.LAYER_TEMP, capi.LAYER_NEXT)
+        ref[d] = s.download_layer(capi.LAYER_NEXT)
+    ref_err = s.eval_div_error(capi.LAYER_TEMP)
+    s.close()
+
+    nranks = 3
+    grp = capi.LocalGroup(g, capi.fluid_params(dtype, *PARAMS), nranks, dtype)
+
+    def work(rank, sv):
+        x0, x1 = slab_range(g.dimx, rank, nranks)
+        sv.upload_layer(capi.LAYER_CUR, [a[x0:x1] for a in cur])
+        sv.upload_layer(capi.LAYER_TEMP, [a[x0:x1] for a in tmp])
+        out = {}
+        for d in (capi.DIR_X, capi.DIR_Y, capi.DIR_Z):
+            sv.sweep(d, DT, capi.LAYER_CUR, capi.LAYER_TEMP, capi.LAYER_NEXT)
+            out[d] = sv.download_layer(capi.LAYER_NEXT)
+        return out, sv.eval_div_error(capi.LAYER_TEMP)
+    res = grp.run(work)
+    grp.close()
+    for d in ref:
+        for v in range(4):
+            got = np.concatenate([res[r][0][d][v] for r in range(nranks)], axis=0)
+            assert np.array_equal(ref[d][v], got), "dir %d field %d" % (d, v)
+    for r in range(nranks):
+        assert res[r][1][1] == ref_err[1]
+        np.testing.assert_allclose(res[r][1][0], ref_err[0], rtol=1e-12)
