@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfs3d_hip.so")
+LIB_PATH = os.environ.get("FS3D_LIB_PATH") or os.path.join(_HERE, "libfs3d_hip.so")   # override: kernel experiments
 
 F32, F64 = 0, 1
 OK, ERR_INVALID, ERR_HIP, ERR_DIVERGED, ERR_UNSUPPORTED, ERR_COMM = range(6)

@@ -23,6 +23,8 @@
 // the 6 words/cell of c',d' that a thread-per-line kernel spills stay on chip (128 VGPRs
 // per lane + 128 KiB LDS per workgroup for a 256-cell fp32 line).
 #include <algorithm>
+#include <type_traits>
+#include <utility>
 #include "fs3d_rows.h"
 
 #define PIPE_NW 8
@@ -30,6 +32,14 @@
 #define FS3D_Z_TILE_STORE 1   // Z sweep: scatter through the LDS tile in whole 64-byte row pieces
 #endif
 
+
+// Compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>).  The sub-pass loops of the
+// P and O phases are too large for `#pragma unroll` (the unroller gives up past its size threshold, the cell
+// indices of the register arrays turn dynamic and the arrays land in scratch memory): instantiate them instead.
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -54,7 +64,11 @@ template <> struct Buf<double> {
 template <typename R, int DIR, int CH>
 struct Chunk {
     static constexpr int VW = 16 / sizeof(R);          // elements per 16-byte vector
-    static constexpr int PC = 64 / sizeof(R) < CH ? 64 / sizeof(R) : CH;   // cells per sub-pass (64 bytes of a Z line)
+#ifndef FS3D_PC_BYTES_XY
+#define FS3D_PC_BYTES_XY 64
+#endif
+    static constexpr int PCB = DIR == 2 ? 64 : FS3D_PC_BYTES_XY;       // bytes of a line per sub-pass (Z: 64-byte row pieces)
+    static constexpr int PC = PCB / sizeof(R) < CH ? PCB / sizeof(R) : CH;   // cells per sub-pass
     static constexpr int NPASS = CH / PC;
     static constexpr int PR = PC / VW;                 // 16-byte pieces per tile row
     static constexpr int RPI = 64 / PR;                // tile rows covered by one wave-wide vector access
@@ -72,10 +86,12 @@ struct Chunk {
     bool zvec;                 // Z: vector/LDS-transposed path usable (dimz % VW == 0)
     R *tile;                   // Z: this wave's [66][PC+1] LDS tile
 
-    // descriptor of a layer field given the pointer to its first OWNED cell (one halo plane precedes it)
-    __device__ __forceinline__ rsrc_t field(const R *first_owned, long long plane) const
+    // ONE descriptor per layer (4 SGPRs) instead of one per field: a field is addressed by adding its byte
+    // offset fo = v * fsb to the wave-uniform offset.  21 descriptors would not fit the SGPR file.
+    unsigned fsb;              // bytes between consecutive fields of a layer
+    __device__ __forceinline__ rsrc_t layer(const R *first_owned, long long plane) const
     {
-        return __builtin_amdgcn_make_buffer_rsrc((void *)(first_owned - plane), 0, (int)fbytes, 0x00020000);
+        return __builtin_amdgcn_make_buffer_rsrc((void *)(first_owned - plane), 0, (int)(4u * fsb), 0x00020000);
     }
     // byte offset of cell s0+t of lane 0, cell index clamped into the line
     __device__ __forceinline__ unsigned soff(int t) const
@@ -135,10 +151,10 @@ struct Chunk {
         }
     }
     // the two cells just outside [c0, c0+PC) (clamped into the line)
-    __device__ __forceinline__ void load_halo(rsrc_t f, int c0, R &lo, R &hi) const
+    __device__ __forceinline__ void load_halo(rsrc_t f, unsigned fo, int c0, R &lo, R &hi) const
     {
-        lo = Buf<R>::ld(f, vob, soff(c0 - 1));
-        hi = Buf<R>::ld(f, vob, soff(c0 + PC));
+        lo = Buf<R>::ld(f, vob, soff(c0 - 1) + fo);
+        hi = Buf<R>::ld(f, vob, soff(c0 + PC) + fo);
     }
     // one cell of this lane (any field-relative uniform byte offset)
     __device__ __forceinline__ R at(rsrc_t f, unsigned so) const { return Buf<R>::ld(f, vob, so); }
@@ -148,7 +164,7 @@ struct Chunk {
     // scatter in[0..PC) to cells [c0, c0+PC) of a field where wmask bit t is set (all: every valid cell is written).
     // Z sweep, all cells written: transpose through the LDS tile and store element-wide, each wave-instruction
     // covering 64/PC whole tile rows of PC contiguous cells (full 64-byte segments).
-    __device__ __forceinline__ void store(rsrc_t f, int c0, const R (&in)[PC], unsigned wmask, bool all, Keep &) const
+    __device__ __forceinline__ void store(rsrc_t f, unsigned fo, int c0, const R (&in)[PC], unsigned wmask, bool all, Keep &) const
     {
         if (DIR == 2 && zvec && all && FS3D_Z_TILE_STORE) {
             constexpr int RPS = 64 / PC;                        // tile rows per store instruction
@@ -163,13 +179,13 @@ struct Chunk {
                 const int row = r * RPS + rsub;
                 const R val = trow[r * RPS * TSTRIDE];
                 const bool ok = col_ok && row < rows_valid;
-                Buf<R>::st(f, ok ? (unsigned)(row * dimz + s0 + c0 + col) * (unsigned)sizeof(R) : BUF_OOB, row0, val);
+                Buf<R>::st(f, ok ? (unsigned)(row * dimz + s0 + c0 + col) * (unsigned)sizeof(R) : BUF_OOB, row0 + fo, val);
             }
         } else {
 #pragma unroll
             for (int t = 0; t < PC; t++) {
                 const bool ok = lane_valid && cell_ok(c0 + t) && ((wmask >> t) & 1u);
-                Buf<R>::st(f, ok ? vob : BUF_OOB, soff(c0 + t), in[t]);
+                Buf<R>::st(f, ok ? vob : BUF_OOB, soff(c0 + t) + fo, in[t]);
             }
         }
     }
@@ -239,6 +255,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
         const int lc = l < la_len ? lane : la_len - 1 - tile_id * 64;   // clamp lanes past the lane axis
         ck.vob = (unsigned)(DIR == 2 ? lc * p.dimz : lc) * (unsigned)sizeof(R);
         ck.fbytes = (unsigned)((p.nstride + 2 * p.plane) * (long long)sizeof(R));
+        ck.fsb = (unsigned)(p.fstride * (long long)sizeof(R));
     }
     ck.dimz = p.dimz;
     ck.rows_valid = la_len - tile_id * 64 < 64 ? la_len - tile_id * 64 : 64;
@@ -252,17 +269,18 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
     const int sob = (int)(so * (long long)sizeof(R));           // byte step to the neighbouring `o` plane/row
     const unsigned vslb = (unsigned)vsl * (unsigned)sizeof(R);  // byte step to a lane-axis neighbour
     // node values / cell codes have no halo plane: same offsets minus one plane
-    const rsrc_t rNode[4] = {
-        __builtin_amdgcn_make_buffer_rsrc((void *)(p.node(0) - p.plane), 0, (int)ck.fbytes, 0x00020000),
-        __builtin_amdgcn_make_buffer_rsrc((void *)(p.node(1) - p.plane), 0, (int)ck.fbytes, 0x00020000),
-        __builtin_amdgcn_make_buffer_rsrc((void *)(p.node(2) - p.plane), 0, (int)ck.fbytes, 0x00020000),
-        __builtin_amdgcn_make_buffer_rsrc((void *)(p.node(3) - p.plane), 0, (int)ck.fbytes, 0x00020000)};
+    const unsigned nsb = (unsigned)(p.nstride * (long long)sizeof(R));      // bytes between the node-value fields
+    const rsrc_t rNode = __builtin_amdgcn_make_buffer_rsrc((void *)(p.node_ - p.plane), 0, (int)(3u * nsb + ck.fbytes), 0x00020000);
+    const unsigned fsb = ck.fsb;
+    const rsrc_t Lcur = ck.layer(p.cur_, p.plane), Ltmp = ck.layer(p.temp_, p.plane);
+    const rsrc_t Lnext = ck.layer(p.next_, p.plane), Ltout = ck.layer(p.temp_out_, p.plane);
     const rsrc_t rCode = __builtin_amdgcn_make_buffer_rsrc((void *)(p.code - p.plane), 0, (int)(ck.fbytes / (sizeof(R) / 2)), 0x00020000);
 
     // per-cell register storage: q -> c'_uvw -> x_T ; dU,dV,dW -> d'_U,d'_V,d'_W -> x_U,x_V,x_W
     R st0[CH], st1[CH], st2[CH], st3[CH];
     unsigned cpack[(CH + 7) / 8];
     unsigned inmask = 0, segmask = 0, intmask = 0;         // NODE_IN cells; cells on a segment; INTERIOR rows (CH <= 32)
+    unsigned umask = 0;                                    // wave-uniform: INTERIOR on all lines of the bundle
 #pragma unroll
     for (int i = 0; i < (CH + 7) / 8; i++) cpack[i] = 0;
 
@@ -287,20 +305,30 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
             if ((code & 3) != ROW_SKIP) segmask |= 1u << t;
             if ((code & 3) == ROW_INTERIOR) intmask |= 1u << t;
         }
+        {
+            // cells that are INTERIOR rows on every line of the bundle: AND over the lanes (lanes past the lane axis
+            // do not care).  Wave-uniform, so the fast paths below are plain scalar branches.
+            unsigned m = lane_valid ? intmask : 0xFFFFFFFFu;
+#pragma unroll
+            for (int k = 1; k < 64; k <<= 1) m &= (unsigned)__shfl_xor((int)m, k, 64);
+            umask = (unsigned)__builtin_amdgcn_readfirstlane((int)m);
+        }
         const R two_ds = p.two_ds[DIR];
         constexpr int M1 = DIR == 0 ? 1 : 0;          // axis of the `o` neighbours
         constexpr int M2 = DIR == 2 ? 1 : 2;          // axis of the lane neighbours
-        const rsrc_t tS = ck.field(p.temp(DIR), p.plane);
-#pragma unroll
-        for (int pass = 0; pass < CK::NPASS; pass++) {
-            const int c0 = pass * PC;
+        const rsrc_t tS = Ltmp;
+        const unsigned foS = (unsigned)DIR * fsb;
+        // One sub-pass of PC cells.  FAST: every cell of the sub-pass is an INTERIOR row on every line of the
+        // bundle (wave-uniform, the common case away from walls): no row-kind tests, no node-value loads.
+        auto p_pass = [&](auto fast_tag, const int c0) __attribute__((always_inline)) {
+            constexpr bool FAST = decltype(fast_tag)::value;
             R gS[PC], x1[PC], x2[PC];                  // d(Vs)/ds, d(Vs)/d(o axis), d(Vs)/d(lane axis)
             R q[PC];
             {
                 // advecting component Vs = temp[DIR]: q, its s-derivative and its lane-axis derivative
                 R a_lo, a_hi;
-                ck.template load<true>(tS, 0, c0, gS);
-                ck.load_halo(tS, c0, a_lo, a_hi);
+                ck.template load<true>(tS, foS, c0, gS);
+                ck.load_halo(tS, foS, c0, a_lo, a_hi);
 #pragma unroll
                 for (int t = 0; t < PC; t++) {
                     // lane-axis neighbours of Vs.  X/Y: the same rows one element left/right (same cache lines
@@ -312,18 +340,18 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
                         l_lo = lo_edge ? e_lo : l_lo;
                         l_hi = hi_edge ? e_hi : l_hi;
                     } else {
-                        l_lo = ck.at(tS, ck.soff(c0 + t) - vslb);
-                        l_hi = ck.at(tS, ck.soff(c0 + t) + vslb);
+                        l_lo = ck.at(tS, ck.soff(c0 + t) + foS - vslb);
+                        l_hi = ck.at(tS, ck.soff(c0 + t) + foS + vslb);
                     }
-                    q[t] = ((intmask >> (c0 + t)) & 1u) ? gS[t] / two_ds : R(0);     // temp->Vs / (2*ds)
+                    q[t] = (FAST || ((intmask >> (c0 + t)) & 1u)) ? gS[t] / two_ds : R(0);     // temp->Vs / (2*ds)
                     x2[t] = (l_hi - l_lo) / p.two_ds[M2];
                 }
                 CK::deriv_inplace(gS, a_lo, a_hi, two_ds);
             }
             {
                 R c[PC];
-                ck.load(tS, sob, c0, x1);
-                ck.load(tS, -sob, c0, c);
+                ck.load(tS, (int)foS + sob, c0, x1);
+                ck.load(tS, (int)foS - sob, c0, c);
 #pragma unroll
                 for (int t = 0; t < PC; t++) x1[t] = (x1[t] - c[t]) / p.two_ds[M1];
             }
@@ -337,9 +365,8 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
                     for (int t = 0; t < PC; t++) g[t] = gS[t];
                 } else {
                     R a_lo, a_hi;
-                    const rsrc_t tv_ = ck.field(p.temp(v), p.plane);
-                    ck.load(tv_, 0, c0, g);
-                    ck.load_halo(tv_, c0, a_lo, a_hi);
+                    ck.load(Ltmp, (int)(v * fsb), c0, g);
+                    ck.load_halo(Ltmp, v * fsb, c0, a_lo, a_hi);
                     CK::deriv_inplace(g, a_lo, a_hi, two_ds);
                 }
 #pragma unroll
@@ -356,9 +383,8 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
             R gT[PC];
             {
                 R a_lo, a_hi;
-                const rsrc_t tT = ck.field(p.temp(3), p.plane);
-                ck.load(tT, 0, c0, gT);
-                ck.load_halo(tT, c0, a_lo, a_hi);
+                ck.load(Ltmp, (int)(3 * fsb), c0, gT);
+                ck.load_halo(Ltmp, 3 * fsb, c0, a_lo, a_hi);
                 CK::deriv_inplace(gT, a_lo, a_hi, two_ds);
 #pragma unroll
                 for (int t = 0; t < PC; t++) gT[t] = p.v_T * gT[t];
@@ -366,30 +392,30 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
             {
                 // T right-hand side -> LDS
                 R cT[PC];
-                ck.load(ck.field(p.cur(3), p.plane), 0, c0, cT);
+                ck.load(Lcur, (int)(3 * fsb), c0, cT);
 #pragma unroll
                 for (int t = 0; t < PC; t++) {
                     const int code = (cpack[(c0 + t) >> 3] >> (4 * ((c0 + t) & 7))) & 0xF;
                     const int kind = code & 3;
                     R d3 = R(0);
-                    if (kind == ROW_INTERIOR) d3 = cT[t] * R(3) / p.dt + acc[t];
-                    else if (kind != ROW_SKIP && !(code & ROW_TEMPFREE)) d3 = ck.at(rNode[3], ck.soff(c0 + t));   // ApplyBC0/1: node T
+                    if (FAST || kind == ROW_INTERIOR) d3 = cT[t] * R(3) / p.dt + acc[t];
+                    else if (kind != ROW_SKIP && !(code & ROW_TEMPFREE)) d3 = ck.at(rNode, ck.soff(c0 + t) + 3 * nsb);   // ApplyBC0/1: node T
                     myD[(c0 + t) * 64] = d3;
                 }
             }
 #pragma unroll
             for (int v = 0; v < 3; v++) {
                 R cV[PC];
-                ck.load(ck.field(p.cur(v), p.plane), 0, c0, cV);
+                ck.load(Lcur, (int)(v * fsb), c0, cV);
 #pragma unroll
                 for (int t = 0; t < PC; t++) {
                     const int code = (cpack[(c0 + t) >> 3] >> (4 * ((c0 + t) & 7))) & 0xF;
                     const int kind = code & 3;
                     R d = R(0);
-                    if (kind == ROW_INTERIOR) {
+                    if (FAST || kind == ROW_INTERIOR) {
                         d = cV[t] * R(3) / p.dt;
                         if (v == DIR) d = d - gT[t];
-                    } else if (kind != ROW_SKIP && !(code & ROW_VELFREE)) d = ck.at(rNode[v], ck.soff(c0 + t));   // ApplyBC0/1: node velocity
+                    } else if (kind != ROW_SKIP && !(code & ROW_VELFREE)) d = ck.at(rNode, ck.soff(c0 + t) + v * nsb);   // ApplyBC0/1: node velocity
                     if (v == 0) st1[c0 + t] = d;
                     if (v == 1) st2[c0 + t] = d;
                     if (v == 2) st3[c0 + t] = d;
@@ -398,7 +424,13 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
 #pragma unroll
             for (int t = 0; t < PC; t++) st0[c0 + t] = q[t];
             __builtin_amdgcn_sched_barrier(0);   // pass boundary
-        }
+        };
+        static_for<CK::NPASS>([&](auto pass_c) __attribute__((always_inline)) {
+            constexpr int c0 = decltype(pass_c)::value * PC;
+            constexpr unsigned PCM = PC >= 32 ? 0xFFFFFFFFu : ((1u << PC) - 1u);
+            if (((umask >> c0) & PCM) == PCM) p_pass(std::true_type{}, c0);
+            else p_pass(std::false_type{}, c0);
+        });
     }
 
     // ------------------------------------------------------------------ F: forward relays, staggered
@@ -411,35 +443,64 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
     //   INTERIOR a = -q - vis, b = 3/dt + 2 vis, c = q - vis      (AdiSolver3D.cpp:760-762)
     //   START    a = 0,  FREE: b = 2, c = -1 ; NOSLIP: b = 1, c = 0 (ApplyBC0, :804-827)
     //   END      c = 0,  FREE: a = -1, b = 2 ; NOSLIP: a = 0, b = 1 (ApplyBC1, :829-852)
-    //   SKIP     identity row.  START and SKIP rows restart the recurrence: the carried c', d' are
-    //   zeroed first, which makes the general step  c' = c/(b - a c'), d' = (d - d' a)/(b - a c')
-    //   (Algorithms.h:28-32) equal to c0/b0, d0/b0 exactly.
+    //   SKIP     identity row.  START and SKIP rows have a = 0, so the general step
+    //   c' = c/(b - a c'), d' = (d - d' a)/(b - a c')  (Algorithms.h:28-32) gives c0/b0, d0/b0 for them whatever
+    //   (finite) c', d' the previous segment left behind: b - 0*c' = b and d - d'*0 = d exactly (the sign of a
+    //   zero d aside).  Likewise END and SKIP rows have c = 0 -> c' = 0 -> x = d' in the back-substitution.
+    // Live-range split by hand: every stored row value passes through a register here.  The rows that the
+    // register allocator parked in scratch during the P phase (its pressure peak) are reloaded now, in bulk and
+    // while the wave waits for its turn anyway, instead of one by one inside the serial chain.
+#define SPLIT8(a, o) asm volatile("" : "+v"(a[o]), "+v"(a[o + 1]), "+v"(a[o + 2]), "+v"(a[o + 3]), "+v"(a[o + 4]), "+v"(a[o + 5]), "+v"(a[o + 6]), "+v"(a[o + 7]))
+#pragma unroll
+    for (int o = 0; o < CH; o += 8) { SPLIT8(st0, o); SPLIT8(st1, o); SPLIT8(st2, o); SPLIT8(st3, o); }
     STAMP(1);
     for (int i = 0; i < w; i++) __syncthreads();
     STAMP(2);
+#define FWD_COEF(VAR, FASTC)                                                                              \
+    {                                                                                                     \
+        const R q = st0[g + i];                                                                           \
+        if (FASTC) { a4[i] = -q - vis; c4[i] = q - vis; b4[i] = bb; }                                     \
+        else {                                                                                            \
+            unsigned cw = cpack[(g + i) >> 3];                                                            \
+            asm volatile("" : "+v"(cw));      /* opaque: no decode results carried from pass to pass */  \
+            const int code = (cw >> (4 * ((g + i) & 7))) & 0xF;                                           \
+            const int kind = code & 3;                                                                    \
+            const bool is_int = kind == ROW_INTERIOR;                                                     \
+            const bool fr = (code & (VAR == 3 ? ROW_TEMPFREE : ROW_VELFREE)) != 0;                        \
+            a4[i] = is_int ? (-q - vis) : ((kind == ROW_END && fr) ? R(-1) : R(0));                       \
+            c4[i] = is_int ? (q - vis) : ((kind == ROW_START && fr) ? R(-1) : R(0));                      \
+            b4[i] = is_int ? bb : (fr ? R(2) : R(1));                                                     \
+        }                                                                                                 \
+    }
 #define FWD_PASS(VAR, DREAD, DWRITE, CWRITE)                                                              \
     {                                                                                                     \
         R cp = R(0), dp = R(0);                                                                           \
         if (w > 0) { cp = relay[(2 * VAR) * 64 + lane]; dp = relay[(2 * VAR + 1) * 64 + lane]; }          \
-        const R vis = VAR == 3 ? p.vis_t : p.vis_v, bb = VAR == 3 ? p.b_t : p.b_v;                        \
-        _Pragma("unroll") for (int t = 0; t < CH; t++) {                                                  \
-            const int code = (cpack[t >> 3] >> (4 * (t & 7))) & 0xF;                                      \
-            const int kind = code & 3;                                                                    \
-            const bool is_int = kind == ROW_INTERIOR, restart = kind == ROW_START || kind == ROW_SKIP;    \
-            const bool fr = (code & (VAR == 3 ? ROW_TEMPFREE : ROW_VELFREE)) != 0;                        \
-            const R q = st0[t];                                                                           \
-            const R a = is_int ? (-q - vis) : ((kind == ROW_END && fr) ? R(-1) : R(0));                   \
-            const R c = is_int ? (q - vis) : ((kind == ROW_START && fr) ? R(-1) : R(0));                  \
-            const R b = is_int ? bb : (fr ? R(2) : R(1));                                                 \
-            const R d = DREAD;                                                                            \
-            if (restart) { cp = R(0); dp = R(0); }                                                        \
-            const R den = b - a * cp;                                                                     \
-            const R num = d - dp * a;                                                                     \
-            cp = c / den;                                                                                 \
-            dp = num / den;                                                                               \
-            DWRITE;                                                                                       \
-            CWRITE;                                                                                       \
-            if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);                                          \
+        R vis = VAR == 3 ? p.vis_t : p.vis_v, bb = VAR == 3 ? p.b_t : p.b_v;                              \
+        /* opaque per pass: otherwise U computes every a, c once and parks them in scratch for V and W */ \
+        asm volatile("" : "+s"(vis), "+s"(bb));                                                           \
+        _Pragma("unroll") for (int g = 0; g < CH; g += 4) {                                               \
+            R a4[4], b4[4], c4[4];                                                                        \
+            /* the group's q values become available only with the chain state of the previous group:   \
+               otherwise the coefficients of the whole chunk are computed up front (96 live registers) */ \
+            asm volatile("" : "+v"(cp), "+v"(dp), "+v"(st0[g]), "+v"(st0[g + 1]), "+v"(st0[g + 2]), "+v"(st0[g + 3])); \
+            /* only the coefficients differ between the two arms; the chain below is common code */      \
+            if (((umask >> g) & 0xFu) == 0xFu) {                                                          \
+                _Pragma("unroll") for (int i = 0; i < 4; i++) FWD_COEF(VAR, true)                         \
+            } else {                                                                                      \
+                _Pragma("unroll") for (int i = 0; i < 4; i++) FWD_COEF(VAR, false)                        \
+            }                                                                                             \
+            _Pragma("unroll") for (int t = g; t < g + 4; t++) {                                           \
+                const R a = a4[t - g], b = b4[t - g], c = c4[t - g];                                      \
+                const R d = DREAD;                                                                        \
+                const R den = b - a * cp;                                                                 \
+                const R num = d - dp * a;                                                                 \
+                cp = c / den;                                                                             \
+                dp = num / den;                                                                           \
+                DWRITE;                                                                                   \
+                CWRITE;                                                                                   \
+            }                                                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                            \
         }                                                                                                 \
         relay[(2 * VAR) * 64 + lane] = cp; relay[(2 * VAR + 1) * 64 + lane] = dp;                         \
     }
@@ -451,6 +512,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
     __syncthreads();
     FWD_PASS(2, st3[t], st3[t] = dp, st0[t] = cp)          // last pass over the cell: c'_uvw replaces q
 #undef FWD_PASS
+#undef FWD_COEF
     STAMP(3);
     for (int i = w + 3; i < PIPE_NW + 3; i++) __syncthreads();
 
@@ -465,12 +527,9 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
         }
 #pragma unroll
         for (int t = CH - 1; t >= 0; t--) {
-            const int s = s0 + t;
-            const int kind = (cpack[t >> 3] >> (4 * (t & 7))) & 3;
             const R c_v = st0[t], c_t = myC[t * 64];
             const R e0 = st1[t], e1 = st2[t], e2 = st3[t], e3 = myD[t * 64];
-            // x[num-1] = d[num-1] (Algorithms.h:34): END and SKIP rows do not look at x[i+1]
-            if (kind == ROW_END || kind == ROW_SKIP) { x[0] = R(0); x[1] = R(0); x[2] = R(0); x[3] = R(0); }
+            // x[num-1] = d[num-1] (Algorithms.h:34): END and SKIP rows carry c' = 0 and so do not look at x[i+1]
             x[0] = e0 - c_v * x[0]; x[1] = e1 - c_v * x[1];   // Algorithms.h:36-37
             x[2] = e2 - c_v * x[2]; x[3] = e3 - c_t * x[3];
             st0[t] = x[3]; st1[t] = x[0]; st2[t] = x[1]; st3[t] = x[2];   // x replaces c',d'
@@ -490,9 +549,8 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
         const int len = n - s0 < 0 ? 0 : (n - s0 > CH ? CH : n - s0);
         const unsigned chunk_mask = len >= 32 ? 0xFFFFFFFFu : ((1u << len) - 1u);
         const bool all_seg = __all((!lane_valid) || ((segmask & chunk_mask) == chunk_mask));
-#pragma unroll
-        for (int pass = 0; pass < CK::NPASS; pass++) {
-            const int c0 = pass * PC;
+        static_for<CK::NPASS>([&](auto pass_c) __attribute__((always_inline)) {
+            constexpr int c0 = decltype(pass_c)::value * PC;
             const unsigned seg_p = segmask >> c0, in_p = inmask >> c0;
             typename CK::Keep keepN, keepT;
 #pragma unroll
@@ -500,18 +558,17 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
                 R xv[PC];
 #pragma unroll
                 for (int t = 0; t < PC; t++) xv[t] = v == 0 ? st1[c0 + t] : (v == 1 ? st2[c0 + t] : (v == 2 ? st3[c0 + t] : st0[c0 + t]));
-                const rsrc_t rNext = ck.field(p.next(v), p.plane);
-                ck.store(rNext, c0, xv, seg_p, all_seg, keepN);
+                ck.store(Lnext, v * fsb, c0, xv, seg_p, all_seg, keepN);
                 if (p.merge) {
                     R tv[PC];
-                    ck.load(ck.field(p.temp(v), p.plane), 0, c0, tv);
+                    ck.load(Ltmp, (int)(v * fsb), c0, tv);
                     CK::pin(keepN); CK::pin(keepT);      // the load returned: every older store has fetched its data
                     if (((in_p & ~seg_p) & (PC >= 32 ? 0xFFFFFFFFu : ((1u << PC) - 1u))) != 0) {
                         // NODE_IN cell outside every segment (run without a closing cell,
                         // Grid3D.cpp:87-117): the reference merges the stale `next` value
 #pragma unroll
                         for (int t = 0; t < PC; t++)
-                            if ((in_p >> t) & ~(seg_p >> t) & 1u) xv[t] = ck.at(rNext, ck.soff(c0 + t));
+                            if ((in_p >> t) & ~(seg_p >> t) & 1u) xv[t] = ck.at(Lnext, ck.soff(c0 + t) + v * fsb);
                     }
 #pragma unroll
                     for (int t = 0; t < PC; t++) {
@@ -520,11 +577,11 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
                             if (p.merge == 2) tv[t] = (tv[t] + xv[t]) / R(2);
                         }
                     }
-                    ck.store(ck.field(p.temp_out(v), p.plane), c0, tv, 0xFFFFFFFFu, true, keepT);
+                    ck.store(Ltout, v * fsb, c0, tv, 0xFFFFFFFFu, true, keepT);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-        }
+        });
     }
     STAMP(7);
 #undef STAMP
@@ -564,6 +621,7 @@ template <>
 bool launch_sweep_pipe<float>(fs3d_ctx *c, int dir, const SweepParams<float> &p)
 {
     const int n = dir == 0 ? p.dimx : (dir == 1 ? p.dimy : p.dimz);
+    if ((unsigned long long)p.fstride * 4ull * sizeof(float) >= (1ull << 32)) return false;   // 32-bit buffer offsets span a layer
     if (n <= PIPE_NW * 16) return launch_dir<float, 16>(c, dir, p);
     if (n <= PIPE_NW * 32) return launch_dir<float, 32>(c, dir, p);
     return false;
@@ -573,6 +631,7 @@ template <>
 bool launch_sweep_pipe<double>(fs3d_ctx *c, int dir, const SweepParams<double> &p)
 {
     const int n = dir == 0 ? p.dimx : (dir == 1 ? p.dimy : p.dimz);
+    if ((unsigned long long)p.fstride * 4ull * sizeof(double) >= (1ull << 32)) return false;
     if (n <= PIPE_NW * 16) return launch_dir<double, 16>(c, dir, p);
     return false;
 }
