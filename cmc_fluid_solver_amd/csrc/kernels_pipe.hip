@@ -318,10 +318,9 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
         constexpr int M2 = DIR == 2 ? 1 : 2;          // axis of the lane neighbours
         const rsrc_t tS = Ltmp;
         const unsigned foS = (unsigned)DIR * fsb;
-        // One sub-pass of PC cells.  FAST: every cell of the sub-pass is an INTERIOR row on every line of the
-        // bundle (wave-uniform, the common case away from walls): no row-kind tests, no node-value loads.
-        auto p_pass = [&](auto fast_tag, const int c0) __attribute__((always_inline)) {
-            constexpr bool FAST = decltype(fast_tag)::value;
+        // One sub-pass of PC cells: the INTERIOR row of every cell (BuildMatrix, AdiSolver3D.cpp:732-802), no
+        // row-kind tests and no node-value loads; p_fix below replaces the rows of the other kinds.
+        auto p_pass = [&](const int c0) __attribute__((always_inline)) {
             R gS[PC], x1[PC], x2[PC];                  // d(Vs)/ds, d(Vs)/d(o axis), d(Vs)/d(lane axis)
             R q[PC];
             {
@@ -343,7 +342,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
                         l_lo = ck.at(tS, ck.soff(c0 + t) + foS - vslb);
                         l_hi = ck.at(tS, ck.soff(c0 + t) + foS + vslb);
                     }
-                    q[t] = (FAST || ((intmask >> (c0 + t)) & 1u)) ? gS[t] / two_ds : R(0);     // temp->Vs / (2*ds)
+                    q[t] = gS[t] / two_ds;                          // temp->Vs / (2*ds)
                     x2[t] = (l_hi - l_lo) / p.two_ds[M2];
                 }
                 CK::deriv_inplace(gS, a_lo, a_hi, two_ds);
@@ -395,12 +394,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
                 ck.load(Lcur, (int)(3 * fsb), c0, cT);
 #pragma unroll
                 for (int t = 0; t < PC; t++) {
-                    const int code = (cpack[(c0 + t) >> 3] >> (4 * ((c0 + t) & 7))) & 0xF;
-                    const int kind = code & 3;
-                    R d3 = R(0);
-                    if (FAST || kind == ROW_INTERIOR) d3 = cT[t] * R(3) / p.dt + acc[t];
-                    else if (kind != ROW_SKIP && !(code & ROW_TEMPFREE)) d3 = ck.at(rNode, ck.soff(c0 + t) + 3 * nsb);   // ApplyBC0/1: node T
-                    myD[(c0 + t) * 64] = d3;
+                    myD[(c0 + t) * 64] = cT[t] * R(3) / p.dt + acc[t];
                 }
             }
 #pragma unroll
@@ -409,13 +403,8 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
                 ck.load(Lcur, (int)(v * fsb), c0, cV);
 #pragma unroll
                 for (int t = 0; t < PC; t++) {
-                    const int code = (cpack[(c0 + t) >> 3] >> (4 * ((c0 + t) & 7))) & 0xF;
-                    const int kind = code & 3;
-                    R d = R(0);
-                    if (FAST || kind == ROW_INTERIOR) {
-                        d = cV[t] * R(3) / p.dt;
-                        if (v == DIR) d = d - gT[t];
-                    } else if (kind != ROW_SKIP && !(code & ROW_VELFREE)) d = ck.at(rNode, ck.soff(c0 + t) + v * nsb);   // ApplyBC0/1: node velocity
+                    R d = cV[t] * R(3) / p.dt;
+                    if (v == DIR) d = d - gT[t];
                     if (v == 0) st1[c0 + t] = d;
                     if (v == 1) st2[c0 + t] = d;
                     if (v == 2) st3[c0 + t] = d;
@@ -425,11 +414,35 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
             for (int t = 0; t < PC; t++) st0[c0 + t] = q[t];
             __builtin_amdgcn_sched_barrier(0);   // pass boundary
         };
+        // Rows that are not INTERIOR (segment ends, cells off every segment): replace what p_pass computed.
+        //   START/END  d = node value (NOSLIP) or 0 (FREE) (ApplyBC0/1, AdiSolver3D.cpp:804-852);  SKIP  d = 0;  q = 0.
+        // Rare (first/last wave of a line, obstacles): node values are fetched for the whole sub-pass unconditionally.
+        auto p_fix = [&](const int c0) __attribute__((always_inline)) {
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                R nv[PC];
+#pragma unroll
+                for (int t = 0; t < PC; t++) nv[t] = ck.at(rNode, ck.soff(c0 + t) + v * nsb);
+#pragma unroll
+                for (int t = 0; t < PC; t++) {
+                    const int code = (cpack[(c0 + t) >> 3] >> (4 * ((c0 + t) & 7))) & 0xF;
+                    const int kind = code & 3;
+                    const bool is_int = kind == ROW_INTERIOR;
+                    const bool noslip = kind != ROW_SKIP && !(code & (v == 3 ? ROW_TEMPFREE : ROW_VELFREE));
+                    const R d = noslip ? nv[t] : R(0);
+                    if (v == 0) st1[c0 + t] = is_int ? st1[c0 + t] : d;
+                    if (v == 1) st2[c0 + t] = is_int ? st2[c0 + t] : d;
+                    if (v == 2) { st3[c0 + t] = is_int ? st3[c0 + t] : d; st0[c0 + t] = is_int ? st0[c0 + t] : R(0); }
+                    if (v == 3) { if (!is_int) myD[(c0 + t) * 64] = d; }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
         static_for<CK::NPASS>([&](auto pass_c) __attribute__((always_inline)) {
             constexpr int c0 = decltype(pass_c)::value * PC;
             constexpr unsigned PCM = PC >= 32 ? 0xFFFFFFFFu : ((1u << PC) - 1u);
-            if (((umask >> c0) & PCM) == PCM) p_pass(std::true_type{}, c0);
-            else p_pass(std::false_type{}, c0);
+            p_pass(c0);                                              // INTERIOR rows for every cell
+            if (((umask >> c0) & PCM) != PCM) p_fix(c0);            // wave-uniform: some line has another row kind here
         });
     }
 
