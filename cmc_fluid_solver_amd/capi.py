@@ -18,7 +18,7 @@ OK, ERR_INVALID, ERR_HIP, ERR_DIVERGED, ERR_UNSUPPORTED, ERR_COMM = range(6)
 DIR_X, DIR_Y, DIR_Z = 0, 1, 2
 LAYER_CUR, LAYER_TEMP, LAYER_HALF, LAYER_NEXT = 0, 1, 2, 3
 SWEEP_AUTO, SWEEP_LINE, SWEEP_PIPE = 0, 1, 2
-OPT_SWEEP_KERNEL, OPT_FUSE_MERGE = 0, 1
+OPT_SWEEP_KERNEL, OPT_FUSE_MERGE, OPT_DIV_CORE = 0, 1, 2
 
 # every symbol include/fs3d.h declares: name -> (restype, argtypes)
 _vp, _i, _d = C.c_void_p, C.c_int, C.c_double

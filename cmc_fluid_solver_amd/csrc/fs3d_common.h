@@ -50,6 +50,7 @@ struct SweepParams {
     R dt;
     R v_T, t_phi;
     unsigned long long *stamps; // measurement only: per-wave phase time stamps (s_memtime), or nullptr
+    int fast_div;               // pipe kernel, fp32: constant divisors are in the range of the division core (kernels_pipe.hip)
     int merge;                  // 0: write next only; 1: also temp_out = merged; 2: merged twice (sweep merge + global merge)
 };
 
@@ -97,6 +98,9 @@ struct fs3d_ctx {
     void *comm = nullptr;          // ncclComm_t
     void *local = nullptr;         // fs3d_local_group* (in-process transport)
     void *carry[4] = {};           // cross-slab X sweep: fwd in/out (6 x plane), bwd in/out (4 x plane)
+    int opt_div_core = 1;          // FS3D_OPT_DIV_CORE
+    int *redo = nullptr;           // pipe kernel, fp32: per-bundle "compute again with full divisions" flags (all zero between sweeps)
+    int redo_cap = 0;
     int rank = 0, nranks = 1;
     int xblocks = 4;               // line blocks of the cross-slab X sweep pipeline (env FS3D_XBLOCKS)
     std::string err;

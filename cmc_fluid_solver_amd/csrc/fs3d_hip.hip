@@ -234,6 +234,7 @@ extern "C" void fs3d_destroy(fs3d_ctx *c)
     if (c->stream) hipStreamSynchronize(c->stream);
     fs3d_comm_destroy(c);
     for (int l = 0; l < 5; l++) if (c->lay[l]) hipFree(c->lay[l]);
+    if (c->redo) hipFree(c->redo);
     if (c->code) hipFree(c->code);
     if (c->node) hipFree(c->node);
     if (c->scr) hipFree(c->scr);
@@ -262,6 +263,7 @@ extern "C" fs3d_status fs3d_set_option(fs3d_ctx *c, int option, int value)
         if (value < FS3D_SWEEP_AUTO || value > FS3D_SWEEP_PIPE) return fail(c, FS3D_ERR_INVALID, "bad sweep kernel id");
         c->opt_kernel = value; return FS3D_OK;
     case FS3D_OPT_FUSE_MERGE: c->opt_fuse = value ? 1 : 0; return FS3D_OK;
+    case FS3D_OPT_DIV_CORE: c->opt_div_core = value ? 1 : 0; return FS3D_OK;
     default: return fail(c, FS3D_ERR_INVALID, "unknown option");
     }
 }
@@ -491,6 +493,9 @@ static void fill_params(fs3d_ctx *c, SweepParams<R> &p, int dir, double dt_, int
     p.dt = dt; p.v_T = (R)c->v_T; p.t_phi = (R)c->t_phi;
     p.merge = merge;
     p.stamps = nullptr;
+    // division core (fp32 pipe kernel): the constant divisors must be plain numbers in [2^-30, 2^60)
+    auto plain = [](double v) { v = v < 0 ? -v : v; return v >= 9.313225746154785e-10 && v < 1.152921504606847e18; };
+    p.fast_div = c->opt_div_core && plain((double)p.two_ds[0]) && plain((double)p.two_ds[1]) && plain((double)p.two_ds[2]) && plain((double)p.dt);
 }
 
 static fs3d_status ensure_scratch(fs3d_ctx *c)

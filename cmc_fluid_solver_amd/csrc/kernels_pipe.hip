@@ -41,6 +41,83 @@ __device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int
 template <int N, typename F>
 __device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
+// Point-to-point hand-off between the waves of a workgroup through an LDS flag (the relay phases): the
+// producer publishes its data, then the flag; the consumer polls the flag, then reads.  DS operations of a wave
+// execute in order; the fences keep the compiler from moving accesses across the flag.  The poll is bounded:
+// a lost hand-off ends in wrong numbers (caught by the parity tests), never in a hung GPU.
+__device__ __forceinline__ void flag_wait(volatile int *f)
+{
+    int guard = 0;
+    while (__builtin_amdgcn_readfirstlane(*f) == 0) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++guard > (1 << 22)) break;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ void flag_set(volatile int *f)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    *f = 1;
+}
+
+// ---- fp32 division without the scaling steps --------------------------------------------------------------
+// The IEEE expansion of x / y on this ISA is  ys = div_scale(y), xs = div_scale(x), r0 = rcp(ys), r = r0 + r0*(1 - ys*r0),
+// q0 = xs*r, q1 = q0 + r*(xs - ys*q0), q2 = div_fmas(xs - ys*q1, r, q1), div_fixup(q2, y, x).  When neither operand
+// needs scaling (no denormal operand or quotient, no overflow, x not tiny) div_scale returns its operand, div_fmas
+// is a plain fma and div_fixup returns q2: the result is exactly the eight-operation core below.  The three
+// scaling/fix-up instructions cost more than the core and, through VCC, keep two divisions from overlapping.
+// `operand_plain(v)`: v == 0 or |v| >= 2^-100 (a zero numerator gives the correctly signed-magnitude zero in the
+// core as well; the sign of a zero result may differ, as elsewhere).  Callers compute with the core, AND the
+// operand tests of a whole group of cells together, and redo the group with the full division when any lane
+// failed -- wave-uniform and rare (values between 0 and 8e-31).  Divisors are checked against [2^-30, 2^60) on
+// the host (constants) or per cell (den); finite fields below 2^60 are assumed (the reference aborts far earlier).
+template <typename R> struct DivC { R y, r; };          // divisor and its refined reciprocal
+__device__ __forceinline__ float recip_refined(float y)
+{
+    float r = __builtin_amdgcn_rcpf(y);
+    const float e = __builtin_fmaf(-y, r, 1.0f);
+    return __builtin_fmaf(e, r, r);
+}
+__device__ __forceinline__ float div_core(float x, float y, float r)
+{
+    float q = x * r;
+    float rem = __builtin_fmaf(-y, q, x);
+    q = __builtin_fmaf(rem, r, q);
+    rem = __builtin_fmaf(-y, q, x);
+    return __builtin_fmaf(rem, r, q);
+}
+// The operand tests are running minima (two VALU operations per operand, one register each, no lane masks):
+//   numerators: (bits << 1) - 2, which wraps a zero to the top;  divisors: bits << 1.  Compared once at the end.
+struct DivGuard {
+    unsigned num_min = 0xFFFFFFFFu, den_min = 0xFFFFFFFFu;
+    __device__ __forceinline__ void num(float v) { const unsigned t = (__builtin_bit_cast(unsigned, v) << 1) - 2u; num_min = t < num_min ? t : num_min; asm volatile("" : "+v"(num_min)); }   // opaque: reduce now, do not keep every t alive until the end
+    __device__ __forceinline__ void den(float v) { const unsigned t = __builtin_bit_cast(unsigned, v) << 1; den_min = t < den_min ? t : den_min; asm volatile("" : "+v"(den_min)); }
+    __device__ __forceinline__ void num(double) {}
+    __device__ __forceinline__ void den(double) {}
+    __device__ __forceinline__ bool plain() const { return num_min >= 2u * (27u << 23) - 2u && den_min >= 2u * (97u << 23); }   // 2^-100, 2^-30
+};
+// x / c.y: FASTM -> core + operand test; otherwise the full division
+template <bool FASTM> __device__ __forceinline__ float divc(float x, const DivC<float> &c, DivGuard &ok)
+{
+    if (FASTM) { ok.num(x); return div_core(x, c.y, c.r); }
+    return x / c.y;
+}
+template <bool FASTM> __device__ __forceinline__ double divc(double x, const DivC<double> &c, DivGuard &) { return x / c.y; }
+__device__ __forceinline__ DivC<float> mkdiv(float y) { return {y, recip_refined(y)}; }
+__device__ __forceinline__ DivC<double> mkdiv(double y) { return {y, 0.0}; }
+// one cell of the forward chain with the division core: c' = c/den, d' = num/den share the reciprocal of den
+__device__ __forceinline__ void chain_core(float c, float num, float den, float &cp, float &dp, DivGuard &ok)
+{
+    ok.den(den); ok.num(c); ok.num(num);
+    const float r = recip_refined(den);
+    float qc = c * r, qd = num * r;
+    float rc = __builtin_fmaf(-den, qc, c), rd = __builtin_fmaf(-den, qd, num);
+    qc = __builtin_fmaf(rc, r, qc); qd = __builtin_fmaf(rd, r, qd);
+    rc = __builtin_fmaf(-den, qc, c); rd = __builtin_fmaf(-den, qd, num);
+    cp = __builtin_fmaf(rc, r, qc); dp = __builtin_fmaf(rd, r, qd);
+}
+__device__ __forceinline__ void chain_core(double c, double num, double den, double &cp, double &dp, DivGuard &) { cp = c / den; dp = num / den; }
+
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
@@ -81,9 +158,9 @@ struct Chunk {
     unsigned ssb;              // byte stride along the sweep
     unsigned vob;              // per-lane byte offset, clamped into the tile for lanes past the lane axis: loads are
                                // UNCONDITIONAL (a predicated load costs a branch and an s_waitcnt vmcnt(0) at its join)
+    unsigned vob_st;           // vob for valid lanes, BUF_OOB for lanes past the lane axis: stores of cells known to be in the line
     unsigned fbytes;           // bytes of one field incl. both halo planes (descriptor range)
     int dimz, rows_valid;      // Z: row pitch (elements), number of valid tile rows
-    bool zvec;                 // Z: vector/LDS-transposed path usable (dimz % VW == 0)
     R *tile;                   // Z: this wave's [66][PC+1] LDS tile
 
     // ONE descriptor per layer (4 SGPRs) instead of one per field: a field is addressed by adding its byte
@@ -102,43 +179,59 @@ struct Chunk {
     }
     __device__ __forceinline__ bool cell_ok(int t) const { return s0 + t < n; }
 
-    // values of a field (+ uniform byte offset dub) at cells [c0, c0+PC) of the chunk -> out[0..PC).
+    // One field of a sub-pass in flight: X/Y hold the PC values themselves, Z the raw 16-byte row pieces that
+    // still have to go through the transposition tile.  `issue` only starts the loads, `land` delivers out[0..PC):
+    // the P phase issues the next field before it lands and consumes the current one (software pipeline).
+    struct Raw { R v[DIR == 2 ? 1 : PC]; u32x4 q[DIR == 2 ? PR : 1]; u32x4 qe; R lo, hi; };
+    // values of a field (+ uniform byte offset dub) at cells [c0, c0+PC) of the chunk.
     // Cells past the end of the line and lanes past the lane axis receive clamped (valid, meaningless) data.
-    // EDGES (Z only): also fetch the lines just below/above the tile into tile rows 64 and 65.
-    template <bool EDGES = false>
-    __device__ __forceinline__ void load(rsrc_t f, int dub, int c0, R (&out)[PC]) const
+    // EDGES (Z only): also fetch the lines just below/above the tile (-> tile rows 64 and 65 in land()).
+    // HALO: also the two cells just outside [c0, c0+PC) on the own line (clamped into the line).
+    template <bool EDGES, bool HALO>
+    __device__ __forceinline__ void issue(rsrc_t f, int dub, int c0, Raw &r) const
     {
-        __builtin_amdgcn_sched_barrier(0);   // the previous field's consumers stay above this field's loads (register budget)
-        if (DIR == 2 && zvec) {
+        if (DIR == 2) {
             const int piece = lane % PR, rsub = lane / PR;
             int pos = s0 + c0 + piece * VW;                 // first cell of this lane's 16-byte piece
             pos = pos > n - VW ? n - VW : pos;
-            u32x4 v[PR], ve;
 #pragma unroll
-            for (int r = 0; r < PR; r++) {
-                int row = r * RPI + rsub;
+            for (int i = 0; i < PR; i++) {
+                int row = i * RPI + rsub;
                 row = row > rows_valid - 1 ? rows_valid - 1 : row;
-                v[r] = __builtin_amdgcn_raw_buffer_load_b128(f, (unsigned)(row * dimz + pos) * (unsigned)sizeof(R), row0 + dub, 0);
+                r.q[i] = __builtin_amdgcn_raw_buffer_load_b128(f, (unsigned)(row * dimz + pos) * (unsigned)sizeof(R), row0 + dub, 0);
             }
             if (EDGES) {
                 // lanes [0,PR): the line below the tile (row -1); lanes [PR,2PR): the line above (row rows_valid)
                 const int erow = rsub == 0 ? 0 : rows_valid + 1;
-                ve = __builtin_amdgcn_raw_buffer_load_b128(f, (unsigned)(erow * dimz + pos) * (unsigned)sizeof(R),
-                                                           row0 + dub - (unsigned)dimz * (unsigned)sizeof(R), 0);
+                r.qe = __builtin_amdgcn_raw_buffer_load_b128(f, (unsigned)(erow * dimz + pos) * (unsigned)sizeof(R),
+                                                             row0 + dub - (unsigned)dimz * (unsigned)sizeof(R), 0);
             }
-            __builtin_amdgcn_sched_barrier(0);   // every load of the field is in flight before the first consumer
-            R *const trow = tile + (rsub * TSTRIDE + piece * VW);      // + r*RPI*TSTRIDE + k: immediate offsets
+        } else {
+#pragma unroll
+            for (int t = 0; t < PC; t++) r.v[t] = Buf<R>::ld(f, vob, soff(c0 + t) + dub);
+        }
+        if (HALO) {
+            r.lo = Buf<R>::ld(f, vob, soff(c0 - 1) + dub);
+            r.hi = Buf<R>::ld(f, vob, soff(c0 + PC) + dub);
+        }
+    }
+    template <bool EDGES>
+    __device__ __forceinline__ void land(const Raw &r, R (&out)[PC]) const
+    {
+        if (DIR == 2) {
+            const int piece = lane % PR, rsub = lane / PR;
+            R *const trow = tile + (rsub * TSTRIDE + piece * VW);      // + i*RPI*TSTRIDE + k: immediate offsets
             R *const tcol = tile + lane * TSTRIDE;
 #pragma unroll
-            for (int r = 0; r < PR; r++) {
+            for (int i = 0; i < PR; i++) {
                 R e[VW];
-                __builtin_memcpy(e, &v[r], 16);
+                __builtin_memcpy(e, &r.q[i], 16);
 #pragma unroll
-                for (int k = 0; k < VW; k++) trow[r * RPI * TSTRIDE + k] = e[k];
+                for (int k = 0; k < VW; k++) trow[i * RPI * TSTRIDE + k] = e[k];
             }
             if (EDGES && rsub < 2) {
                 R e[VW];
-                __builtin_memcpy(e, &ve, 16);
+                __builtin_memcpy(e, &r.qe, 16);
 #pragma unroll
                 for (int k = 0; k < VW; k++) trow[64 * TSTRIDE + k] = e[k];
             }
@@ -146,9 +239,18 @@ struct Chunk {
             for (int t = 0; t < PC; t++) out[t] = tcol[t];
         } else {
 #pragma unroll
-            for (int t = 0; t < PC; t++) out[t] = Buf<R>::ld(f, vob, soff(c0 + t) + dub);
-            __builtin_amdgcn_sched_barrier(0);   // every load of the field is in flight before the first consumer
+            for (int t = 0; t < PC; t++) out[t] = r.v[t];
         }
+    }
+    // issue + land in one go (O phase)
+    template <bool EDGES = false>
+    __device__ __forceinline__ void load(rsrc_t f, int dub, int c0, R (&out)[PC]) const
+    {
+        Raw r;
+        __builtin_amdgcn_sched_barrier(0);   // the previous field's consumers stay above this field's loads (register budget)
+        issue<EDGES, false>(f, dub, c0, r);
+        __builtin_amdgcn_sched_barrier(0);   // every load of the field is in flight before the first consumer
+        land<EDGES>(r, out);
     }
     // the two cells just outside [c0, c0+PC) (clamped into the line)
     __device__ __forceinline__ void load_halo(rsrc_t f, unsigned fo, int c0, R &lo, R &hi) const
@@ -166,7 +268,7 @@ struct Chunk {
     // covering 64/PC whole tile rows of PC contiguous cells (full 64-byte segments).
     __device__ __forceinline__ void store(rsrc_t f, unsigned fo, int c0, const R (&in)[PC], unsigned wmask, bool all, Keep &) const
     {
-        if (DIR == 2 && zvec && all && FS3D_Z_TILE_STORE) {
+        if (DIR == 2 && all && FS3D_Z_TILE_STORE) {
             constexpr int RPS = 64 / PC;                        // tile rows per store instruction
             const int col = lane % PC, rsub = lane / PC;
             R *const tcol = tile + lane * TSTRIDE;
@@ -189,25 +291,41 @@ struct Chunk {
             }
         }
     }
+    // store of a sub-pass whose cells are all inside the line and all written (wave-uniform fast path of the O phase)
+    __device__ __forceinline__ void store_plain(rsrc_t f, unsigned fo, int c0, const R (&in)[PC]) const
+    {
+        if (DIR == 2 && FS3D_Z_TILE_STORE) { Keep k; store(f, fo, c0, in, 0xFFFFFFFFu, true, k); }
+        else {
+#pragma unroll
+            for (int t = 0; t < PC; t++) Buf<R>::st(f, vob_st, soff(c0 + t) + fo, in[t]);
+        }
+    }
     // central difference along the sweep, in place: a[t] <- (a[t+1] - a[t-1]) / two_ds   (TimeLayer3D.h:338-340)
-    __device__ __forceinline__ static void deriv_inplace(R (&a)[PC], R a_lo, R a_hi, R two_ds)
+    template <bool FASTM>
+    __device__ __forceinline__ static void deriv_inplace(R (&a)[PC], R a_lo, R a_hi, const DivC<R> &two_ds, DivGuard &ok)
     {
         R prev = a_lo;
 #pragma unroll
         for (int t = 0; t < PC; t++) {
             const R cur = a[t];
             const R nxt = t == PC - 1 ? a_hi : a[t == PC - 1 ? t : t + 1];
-            a[t] = (nxt - prev) / two_ds;
+            a[t] = divc<FASTM>(nxt - prev, two_ds, ok);
             prev = cur;
+            if (FASTM && (t & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // the core has no VCC to serialise it: bound the overlap
         }
     }
 };
 
 // one workgroup = one bundle
-template <typename R, int DIR, int CH>
-__global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p, int n_o, int n_tiles)
+// FM (fp32 only): divide with the scaling-free core; a workgroup that met an operand outside the core's range
+// raises redo[bundle] and the FM = false instance, launched right behind with the same arguments, computes that
+// bundle again with full divisions (every other workgroup of it returns at once).
+template <typename R, int DIR, int CH, bool FM>
+__global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p, int n_o, int n_tiles, int *redo)
 {
+    if (!FM && redo && redo[blockIdx.x] == 0) return;      // redo pass: this bundle was fine
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    DivGuard ok;                                            // FM: were all division operands so far in the core's range?
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave id, kept scalar
 
@@ -242,6 +360,17 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
     R *ldsD = (R *)smem_raw;
     R *ldsC = ldsD + LDS_D;
     R *relay = ldsC + LDS_C;                                // 8 x 64 forward (c', d' per pass), reused 4 x 64 backward
+    volatile int *fflag = (volatile int *)(relay + 8 * 64); // [4 passes][NW]: forward pass k of wave w is done
+    volatile int *bflag = fflag + 4 * PIPE_NW;              // [NW]: backward pass of wave w is done
+    if (threadIdx.x < 5 * PIPE_NW) fflag[threadIdx.x] = 0;
+    __syncthreads();                                        // the only workgroup-wide barrier of the kernel
+#ifndef FS3D_NO_P_PRIO
+    // The relay visits the waves in order, so the low waves are needed first: give them the issue slots first.
+    // It also takes the waves out of lockstep (they would otherwise all wait for memory at the same time).
+    if (w < 2) __builtin_amdgcn_s_setprio(3);
+    else if (w < 4) __builtin_amdgcn_s_setprio(2);
+    else if (w < 6) __builtin_amdgcn_s_setprio(1);
+#endif
 
     Chunk<R, DIR, CH> ck;
     ck.n = n; ck.s0 = w * CH; ck.lane = lane; ck.lane_valid = l < la_len;
@@ -256,10 +385,10 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
         ck.vob = (unsigned)(DIR == 2 ? lc * p.dimz : lc) * (unsigned)sizeof(R);
         ck.fbytes = (unsigned)((p.nstride + 2 * p.plane) * (long long)sizeof(R));
         ck.fsb = (unsigned)(p.fstride * (long long)sizeof(R));
+        ck.vob_st = l < la_len ? ck.vob : BUF_OOB;
     }
     ck.dimz = p.dimz;
     ck.rows_valid = la_len - tile_id * 64 < 64 ? la_len - tile_id * 64 : 64;
-    ck.zvec = (p.dimz % Chunk<R, DIR, CH>::VW) == 0;
     ck.tile = TILE_IN_ROWS ? ldsC + (size_t)w * CH * 64 : ldsC + (size_t)PIPE_NW * CH * 64 + (size_t)w * TILE;
     const int s0 = ck.s0;
     const bool lane_valid = ck.lane_valid;
@@ -318,102 +447,151 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
         constexpr int M2 = DIR == 2 ? 1 : 2;          // axis of the lane neighbours
         const rsrc_t tS = Ltmp;
         const unsigned foS = (unsigned)DIR * fsb;
+        const DivC<R> dS = mkdiv(two_ds), dM1 = mkdiv(p.two_ds[M1]), dM2 = mkdiv(p.two_ds[M2]), dDt = mkdiv(p.dt);
         // One sub-pass of PC cells: the INTERIOR row of every cell (BuildMatrix, AdiSolver3D.cpp:732-802), no
         // row-kind tests and no node-value loads; p_fix below replaces the rows of the other kinds.
+        // Software pipeline over the nine field groups: group k+1 is issued before group k is landed and consumed,
+        // so a wave always has one group of loads in flight while it computes (SB pins that order).
+#define SB __builtin_amdgcn_sched_barrier(0)
+        constexpr int VA = DIR == 0 ? 1 : 0;          // the two components other than the advecting one, ascending
+        constexpr int VB = DIR == 2 ? 1 : 2;
         auto p_pass = [&](const int c0) __attribute__((always_inline)) {
+            typedef typename CK::Raw Raw;
             R gS[PC], x1[PC], x2[PC];                  // d(Vs)/ds, d(Vs)/d(o axis), d(Vs)/d(lane axis)
             R q[PC];
-            {
-                // advecting component Vs = temp[DIR]: q, its s-derivative and its lane-axis derivative
-                R a_lo, a_hi;
-                ck.template load<true>(tS, foS, c0, gS);
-                ck.load_halo(tS, foS, c0, a_lo, a_hi);
+            Raw rS, rP, rM;
+            R l_lo[DIR == 2 ? 1 : PC], l_hi[DIR == 2 ? 1 : PC];
+            // I1: advecting component Vs = temp[DIR] (centre, sweep halo, Z: edge lines), X/Y: its lane neighbours
+            ck.template issue<true, true>(tS, (int)foS, c0, rS);
+            if (DIR != 2) {
 #pragma unroll
                 for (int t = 0; t < PC; t++) {
-                    // lane-axis neighbours of Vs.  X/Y: the same rows one element left/right (same cache lines
-                    // as the centre load).  Z: neighbouring lanes; the wave's two edge lanes read the edge rows.
-                    R l_lo, l_hi;
-                    if (DIR == 2 && ck.zvec) {
-                        l_lo = __shfl_up(gS[t], 1, 64); l_hi = __shfl_down(gS[t], 1, 64);
-                        const R e_lo = ck.tile[64 * CK::TSTRIDE + t], e_hi = ck.tile[65 * CK::TSTRIDE + t];
-                        l_lo = lo_edge ? e_lo : l_lo;
-                        l_hi = hi_edge ? e_hi : l_hi;
-                    } else {
-                        l_lo = ck.at(tS, ck.soff(c0 + t) + foS - vslb);
-                        l_hi = ck.at(tS, ck.soff(c0 + t) + foS + vslb);
-                    }
-                    q[t] = gS[t] / two_ds;                          // temp->Vs / (2*ds)
-                    x2[t] = (l_hi - l_lo) / p.two_ds[M2];
+                    // the same rows one element left/right (same cache lines as the centre load)
+                    l_lo[t] = ck.at(tS, ck.soff(c0 + t) + foS - vslb);
+                    l_hi[t] = ck.at(tS, ck.soff(c0 + t) + foS + vslb);
                 }
-                CK::deriv_inplace(gS, a_lo, a_hi, two_ds);
             }
+            SB;
+            // I2: Vs on the two neighbouring `o` planes/rows
+            ck.template issue<false, false>(tS, (int)foS + sob, c0, rP);
+            ck.template issue<false, false>(tS, (int)foS - sob, c0, rM);
+            SB;
+            // C1: q, d(Vs)/d(lane axis), d(Vs)/ds
+            ck.template land<true>(rS, gS);
+#pragma unroll
+            for (int t = 0; t < PC; t++) {
+                R lo_, hi_;
+                if (DIR == 2) {
+                    // Z: neighbouring lanes; the wave's two edge lanes read the edge rows of the tile
+                    lo_ = __shfl_up(gS[t], 1, 64); hi_ = __shfl_down(gS[t], 1, 64);
+                    const R e_lo = ck.tile[64 * CK::TSTRIDE + t], e_hi = ck.tile[65 * CK::TSTRIDE + t];
+                    lo_ = lo_edge ? e_lo : lo_;
+                    hi_ = hi_edge ? e_hi : hi_;
+                } else { lo_ = l_lo[t]; hi_ = l_hi[t]; }
+                q[t] = divc<FM>(gS[t], dS, ok);                 // temp->Vs / (2*ds)
+                x2[t] = divc<FM>(hi_ - lo_, dM2, ok);
+                if (FM && (t & 1) == 1) SB;
+            }
+            CK::template deriv_inplace<FM>(gS, rS.lo, rS.hi, dS, ok);
+            SB;
+            // I3: first other velocity component
+            Raw rA;
+            ck.template issue<false, true>(Ltmp, (int)(VA * fsb), c0, rA);
+            SB;
+            // C2: d(Vs)/d(o axis)
             {
                 R c[PC];
-                ck.load(tS, (int)foS + sob, c0, x1);
-                ck.load(tS, (int)foS - sob, c0, c);
+                ck.template land<false>(rP, x1);
+                ck.template land<false>(rM, c);
 #pragma unroll
-                for (int t = 0; t < PC; t++) x1[t] = (x1[t] - c[t]) / p.two_ds[M1];
+                for (int t = 0; t < PC; t++) { x1[t] = divc<FM>(x1[t] - c[t], dM1, ok); if (FM && (t & 3) == 3) SB; }
             }
-            // DissFunc{X,Y,Z} (TimeLayer3D.h:554-588): (((tU + tV) + tW) + g_M1*x1) + g_M2*x2, summed in that order
+            SB;
+            // I4: second other velocity component
+            Raw rB;
+            ck.template issue<false, true>(Ltmp, (int)(VB * fsb), c0, rB);
+            SB;
+            // C3: d(V_a)/ds
+            R gA[PC];
+            ck.template land<false>(rA, gA);
+            CK::template deriv_inplace<FM>(gA, rA.lo, rA.hi, dS, ok);
+            SB;
+            // I5: temperature (temp layer)
+            Raw rT;
+            ck.template issue<false, true>(Ltmp, (int)(3 * fsb), c0, rT);
+            SB;
+            // C4: d(V_b)/ds and DissFunc{X,Y,Z} (TimeLayer3D.h:554-588):
+            //     (((tU + tV) + tW) + g_M1*x1) + g_M2*x2, summed in that order
             R acc[PC];
-#pragma unroll
-            for (int v = 0; v < 3; v++) {
-                R g[PC];
-                if (v == DIR) {
-#pragma unroll
-                    for (int t = 0; t < PC; t++) g[t] = gS[t];
-                } else {
-                    R a_lo, a_hi;
-                    ck.load(Ltmp, (int)(v * fsb), c0, g);
-                    ck.load_halo(Ltmp, v * fsb, c0, a_lo, a_hi);
-                    CK::deriv_inplace(g, a_lo, a_hi, two_ds);
-                }
+            {
+                R gB[PC];
+                ck.template land<false>(rB, gB);
+                CK::template deriv_inplace<FM>(gB, rB.lo, rB.hi, dS, ok);
 #pragma unroll
                 for (int t = 0; t < PC; t++) {
-                    const R term = v == DIR ? (R(2) * g[t]) * g[t] : g[t] * g[t];
-                    acc[t] = v == 0 ? term : acc[t] + term;
-                    if (v == M1) x1[t] = g[t] * x1[t];
-                    if (v == M2) x2[t] = g[t] * x2[t];
+                    const R g0 = DIR == 0 ? gS[t] : gA[t];
+                    const R g1 = DIR == 1 ? gS[t] : (DIR == 0 ? gA[t] : gB[t]);
+                    const R g2 = DIR == 2 ? gS[t] : gB[t];
+                    const R t0 = DIR == 0 ? (R(2) * g0) * g0 : g0 * g0;
+                    const R t1 = DIR == 1 ? (R(2) * g1) * g1 : g1 * g1;
+                    const R t2 = DIR == 2 ? (R(2) * g2) * g2 : g2 * g2;
+                    const R gm1 = M1 == 0 ? g0 : g1, gm2 = M2 == 1 ? g1 : g2;
+                    const R y1 = gm1 * x1[t], y2 = gm2 * x2[t];
+                    acc[t] = p.t_phi * ((((t0 + t1) + t2) + y1) + y2);   // t_phi * DissFunc
                 }
             }
-#pragma unroll
-            for (int t = 0; t < PC; t++) acc[t] = p.t_phi * ((acc[t] + x1[t]) + x2[t]);   // t_phi * DissFunc
-            // temperature: gradient along s (momentum RHS, AdiSolver3D.cpp:766/781/796)
+            SB;
+            // I6: temperature (cur layer)
+            Raw rCT;
+            ck.template issue<false, false>(Lcur, (int)(3 * fsb), c0, rCT);
+            SB;
+            // C5: temperature gradient along s (momentum RHS, AdiSolver3D.cpp:766/781/796)
             R gT[PC];
-            {
-                R a_lo, a_hi;
-                ck.load(Ltmp, (int)(3 * fsb), c0, gT);
-                ck.load_halo(Ltmp, 3 * fsb, c0, a_lo, a_hi);
-                CK::deriv_inplace(gT, a_lo, a_hi, two_ds);
+            ck.template land<false>(rT, gT);
+            CK::template deriv_inplace<FM>(gT, rT.lo, rT.hi, dS, ok);
 #pragma unroll
-                for (int t = 0; t < PC; t++) gT[t] = p.v_T * gT[t];
-            }
+            for (int t = 0; t < PC; t++) gT[t] = p.v_T * gT[t];
+            SB;
+            // I7..I9 / C6..C9: the four `cur` fields -> right-hand sides
+            Raw rC0, rC1, rC2;
+            ck.template issue<false, false>(Lcur, 0, c0, rC0);
+            SB;
             {
-                // T right-hand side -> LDS
                 R cT[PC];
-                ck.load(Lcur, (int)(3 * fsb), c0, cT);
+                ck.template land<false>(rCT, cT);
 #pragma unroll
-                for (int t = 0; t < PC; t++) {
-                    myD[(c0 + t) * 64] = cT[t] * R(3) / p.dt + acc[t];
-                }
+                for (int t = 0; t < PC; t++) { myD[(c0 + t) * 64] = divc<FM>(cT[t] * R(3), dDt, ok) + acc[t]; if (FM && (t & 3) == 3) SB; }   // T right-hand side -> LDS
             }
-#pragma unroll
-            for (int v = 0; v < 3; v++) {
+            SB;
+            ck.template issue<false, false>(Lcur, (int)fsb, c0, rC1);
+            SB;
+            {
                 R cV[PC];
-                ck.load(Lcur, (int)(v * fsb), c0, cV);
+                ck.template land<false>(rC0, cV);
 #pragma unroll
-                for (int t = 0; t < PC; t++) {
-                    R d = cV[t] * R(3) / p.dt;
-                    if (v == DIR) d = d - gT[t];
-                    if (v == 0) st1[c0 + t] = d;
-                    if (v == 1) st2[c0 + t] = d;
-                    if (v == 2) st3[c0 + t] = d;
-                }
+                for (int t = 0; t < PC; t++) { R d = divc<FM>(cV[t] * R(3), dDt, ok); if (DIR == 0) d = d - gT[t]; st1[c0 + t] = d; if (FM && (t & 3) == 3) SB; }
+            }
+            SB;
+            ck.template issue<false, false>(Lcur, (int)(2 * fsb), c0, rC2);
+            SB;
+            {
+                R cV[PC];
+                ck.template land<false>(rC1, cV);
+#pragma unroll
+                for (int t = 0; t < PC; t++) { R d = divc<FM>(cV[t] * R(3), dDt, ok); if (DIR == 1) d = d - gT[t]; st2[c0 + t] = d; if (FM && (t & 3) == 3) SB; }
+            }
+            SB;
+            {
+                R cV[PC];
+                ck.template land<false>(rC2, cV);
+#pragma unroll
+                for (int t = 0; t < PC; t++) { R d = divc<FM>(cV[t] * R(3), dDt, ok); if (DIR == 2) d = d - gT[t]; st3[c0 + t] = d; if (FM && (t & 3) == 3) SB; }
             }
 #pragma unroll
             for (int t = 0; t < PC; t++) st0[c0 + t] = q[t];
-            __builtin_amdgcn_sched_barrier(0);   // pass boundary
+            SB;   // pass boundary
         };
+#undef SB
         // Rows that are not INTERIOR (segment ends, cells off every segment): replace what p_pass computed.
         //   START/END  d = node value (NOSLIP) or 0 (FREE) (ApplyBC0/1, AdiSolver3D.cpp:804-852);  SKIP  d = 0;  q = 0.
         // Rare (first/last wave of a line, obstacles): node values are fetched for the whole sub-pass unconditionally.
@@ -467,7 +645,8 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
 #pragma unroll
     for (int o = 0; o < CH; o += 8) { SPLIT8(st0, o); SPLIT8(st1, o); SPLIT8(st2, o); SPLIT8(st3, o); }
     STAMP(1);
-    for (int i = 0; i < w; i++) __syncthreads();
+    __builtin_amdgcn_s_setprio(3);     // the serial chains are latency-critical: ahead of other waves' P/O work
+    if (w > 0) flag_wait(&fflag[3 * PIPE_NW + w - 1]);
     STAMP(2);
 #define FWD_COEF(VAR, FASTC)                                                                              \
     {                                                                                                     \
@@ -488,7 +667,10 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
 #define FWD_PASS(VAR, DREAD, DWRITE, CWRITE)                                                              \
     {                                                                                                     \
         R cp = R(0), dp = R(0);                                                                           \
-        if (w > 0) { cp = relay[(2 * VAR) * 64 + lane]; dp = relay[(2 * VAR + 1) * 64 + lane]; }          \
+        if (w > 0) {                                                                                      \
+            flag_wait(&fflag[VAR * PIPE_NW + w - 1]);                                                     \
+            cp = relay[(2 * VAR) * 64 + lane]; dp = relay[(2 * VAR + 1) * 64 + lane];                     \
+        }                                                                                                 \
         R vis = VAR == 3 ? p.vis_t : p.vis_v, bb = VAR == 3 ? p.b_t : p.b_v;                              \
         /* opaque per pass: otherwise U computes every a, c once and parks them in scratch for V and W */ \
         asm volatile("" : "+s"(vis), "+s"(bb));                                                           \
@@ -508,29 +690,29 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
                 const R d = DREAD;                                                                        \
                 const R den = b - a * cp;                                                                 \
                 const R num = d - dp * a;                                                                 \
-                cp = c / den;                                                                             \
-                dp = num / den;                                                                           \
+                if (FM) chain_core(c, num, den, cp, dp, ok);                                              \
+                else { cp = c / den; dp = num / den; }                                                    \
                 DWRITE;                                                                                   \
                 CWRITE;                                                                                   \
             }                                                                                             \
             __builtin_amdgcn_sched_barrier(0);                                                            \
         }                                                                                                 \
         relay[(2 * VAR) * 64 + lane] = cp; relay[(2 * VAR + 1) * 64 + lane] = dp;                         \
+        flag_set(&fflag[VAR * PIPE_NW + w]);                                                              \
     }
     FWD_PASS(3, myD[t * 64], myD[t * 64] = dp, myC[t * 64] = cp)
-    __syncthreads();
     FWD_PASS(0, st1[t], st1[t] = dp, (void)0)
-    __syncthreads();
     FWD_PASS(1, st2[t], st2[t] = dp, (void)0)
-    __syncthreads();
     FWD_PASS(2, st3[t], st3[t] = dp, st0[t] = cp)          // last pass over the cell: c'_uvw replaces q
 #undef FWD_PASS
+    if (FM) { if (!__all(ok.plain()) && lane == 0) atomicOr(&redo[blockIdx.x], 1); }
 #undef FWD_COEF
     STAMP(3);
-    for (int i = w + 3; i < PIPE_NW + 3; i++) __syncthreads();
 
     // ------------------------------------------------------------------ B: backward relay (registers/LDS only)
-    for (int i = 0; i < PIPE_NW - 1 - w; i++) __syncthreads();
+    // The last wave finishes its last forward pass after every other wave has finished all of theirs (each pass
+    // of wave w waits for the same pass of wave w-1), so the relay slots are free for the way back.
+    if (w < PIPE_NW - 1) flag_wait(&bflag[w + 1]);
     STAMP(4);
     {
         R x[4] = {R(0), R(0), R(0), R(0)};
@@ -550,10 +732,11 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
         }
         relay[0 * 64 + lane] = x[0]; relay[1 * 64 + lane] = x[1];
         relay[2 * 64 + lane] = x[2]; relay[3 * 64 + lane] = x[3];
+        flag_set(&bflag[w]);
     }
+    __builtin_amdgcn_s_setprio(0);
     STAMP(5);
-    // the PIPE_NW-1 hand-off barriers, plus one more: ldsC becomes the transposition tiles again
-    for (int i = PIPE_NW - 1 - w; i < PIPE_NW; i++) __syncthreads();
+    // no barrier: the transposition tiles of the O phase live in the wave's own c'_T rows (or its own region)
     STAMP(6);
 
     // ------------------------------------------------------------------ O: scatter + merge, field by field, PC cells per pass
@@ -565,6 +748,34 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
         static_for<CK::NPASS>([&](auto pass_c) __attribute__((always_inline)) {
             constexpr int c0 = decltype(pass_c)::value * PC;
             const unsigned seg_p = segmask >> c0, in_p = inmask >> c0;
+            constexpr unsigned PCM = PC >= 32 ? 0xFFFFFFFFu : ((1u << PC) - 1u);
+            if (((umask >> c0) & PCM) == PCM) {
+                // every cell of the sub-pass is an INTERIOR row (hence NODE_IN and on a segment) on every line:
+                // unmasked stores, unconditional merge, and the next field's temp values requested one field ahead
+                typename CK::Raw rt[2];
+                if (p.merge) ck.template issue<false, false>(Ltmp, 0, c0, rt[0]);
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
+                    R xv[PC];
+#pragma unroll
+                    for (int t = 0; t < PC; t++) xv[t] = v == 0 ? st1[c0 + t] : (v == 1 ? st2[c0 + t] : (v == 2 ? st3[c0 + t] : st0[c0 + t]));
+                    ck.store_plain(Lnext, v * fsb, c0, xv);
+                    if (p.merge) {
+                        if (v < 3) ck.template issue<false, false>(Ltmp, (int)((v + 1) * fsb), c0, rt[(v + 1) & 1]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        R tv[PC];
+                        ck.template land<false>(rt[v & 1], tv);
+#pragma unroll
+                        for (int t = 0; t < PC; t++) {
+                            tv[t] = (tv[t] + xv[t]) / R(2);                          // MergeFieldTo (TimeLayer3D.h:415-436)
+                            if (p.merge == 2) tv[t] = (tv[t] + xv[t]) / R(2);
+                        }
+                        ck.store_plain(Ltout, v * fsb, c0, tv);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                return;
+            }
             typename CK::Keep keepN, keepT;
 #pragma unroll
             for (int v = 0; v < 4; v++) {
@@ -575,8 +786,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
                 if (p.merge) {
                     R tv[PC];
                     ck.load(Ltmp, (int)(v * fsb), c0, tv);
-                    CK::pin(keepN); CK::pin(keepT);      // the load returned: every older store has fetched its data
-                    if (((in_p & ~seg_p) & (PC >= 32 ? 0xFFFFFFFFu : ((1u << PC) - 1u))) != 0) {
+                    if (((in_p & ~seg_p) & PCM) != 0) {
                         // NODE_IN cell outside every segment (run without a closing cell,
                         // Grid3D.cpp:87-117): the reference merges the stale `next` value
 #pragma unroll
@@ -598,6 +808,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
     }
     STAMP(7);
 #undef STAMP
+    if (!FM && redo && threadIdx.x == 0) redo[blockIdx.x] = 0;   // handled: the flags are all zero again for the next sweep
 }
 
 template <typename R, int DIR, int CH>
@@ -606,16 +817,33 @@ static bool launch_one(fs3d_ctx *c, const SweepParams<R> &p)
     const int la_len = DIR == 2 ? p.dimy : p.dimz;
     const int n_o = DIR == 0 ? p.dimy : p.dimx;
     const int n_tiles = (la_len + 63) / 64;
+    if (DIR == 2 && p.dimz % Chunk<R, DIR, CH>::VW != 0) return false;   // Z moves whole 16-byte row pieces
     const size_t tile = Chunk<R, DIR, CH>::TILE_ELEMS;
     const size_t lds_c = (size_t)PIPE_NW * CH * 64 + (tile <= (size_t)CH * 64 ? 0 : (size_t)PIPE_NW * tile);
-    const size_t lds = ((size_t)PIPE_NW * CH * 64 + lds_c + 8 * 64) * sizeof(R);
+    const size_t lds = ((size_t)PIPE_NW * CH * 64 + lds_c + 8 * 64) * sizeof(R) + 5 * PIPE_NW * sizeof(int);
+    const int grid = n_o * n_tiles;
+    constexpr bool HAS_FM = std::is_same<R, float>::value;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)k_sweep_pipe<R, DIR, CH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void *)k_sweep_pipe<R, DIR, CH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return false;
+        if (HAS_FM && hipFuncSetAttribute((const void *)k_sweep_pipe<R, DIR, CH, HAS_FM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return false;
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_sweep_pipe<R, DIR, CH>), dim3((unsigned)(n_o * n_tiles)), dim3(PIPE_NW * 64), lds, c->stream, p, n_o, n_tiles);
+    if (HAS_FM && p.fast_div) {
+        // division core first; the full-division instance right behind it redoes the bundles that asked for it
+        if (c->redo_cap < grid) {
+            if (c->redo) { hipStreamSynchronize(c->stream); hipFree(c->redo); c->redo = nullptr; c->redo_cap = 0; }
+            if (hipMalloc(&c->redo, (size_t)grid * sizeof(int)) != hipSuccess) return false;
+            if (hipMemsetAsync(c->redo, 0, (size_t)grid * sizeof(int), c->stream) != hipSuccess) return false;
+            c->redo_cap = grid;
+        }
+        hipLaunchKernelGGL((k_sweep_pipe<R, DIR, CH, HAS_FM>), dim3((unsigned)grid), dim3(PIPE_NW * 64), lds, c->stream, p, n_o, n_tiles, c->redo);
+        hipLaunchKernelGGL((k_sweep_pipe<R, DIR, CH, false>), dim3((unsigned)grid), dim3(PIPE_NW * 64), lds, c->stream, p, n_o, n_tiles, c->redo);
+    } else {
+        hipLaunchKernelGGL((k_sweep_pipe<R, DIR, CH, false>), dim3((unsigned)grid), dim3(PIPE_NW * 64), lds, c->stream, p, n_o, n_tiles, (int *)nullptr);
+    }
     return true;
 }
 

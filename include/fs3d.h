@@ -57,7 +57,9 @@ enum {
 };
 enum {
     FS3D_OPT_SWEEP_KERNEL = 0,
-    FS3D_OPT_FUSE_MERGE = 1   /* 1 (default): merge fused into the sweep; 0: separate merge kernels */
+    FS3D_OPT_FUSE_MERGE = 1,  /* 1 (default): merge fused into the sweep; 0: separate merge kernels */
+    FS3D_OPT_DIV_CORE = 2     /* 1 (default): fp32 pipe kernel divides with the scaling-free core of the IEEE expansion and
+                                 falls back to the full division where an operand needs scaling (same results); 0: always full */
 };
 
 /* ---- lifetime ---------------------------------------------------------------

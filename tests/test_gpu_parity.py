@@ -369,3 +369,61 @@ def test_masked_bottom_geometry_matches_oracle(built, dtype):
         rc, eo = o.time_step(dt, cfg.num_global, cfg.num_local, True)
         assert rc == 0 and e == pytest.approx(eo, rel=1e-12)
     assert_layers_equal(s, o, capi.LAYER_CUR, O.L_CUR, "cur")
+
+
+def _scaled_state(g, dtype, scale, seed):
+    """Velocities of the perturbed state multiplied by `scale`, in a band of planes only: normal, tiny and
+    exactly-zero operands side by side in the same bundles."""
+    base = [np.ascontiguousarray(a, dtype) for a in (g.vx, g.vy, g.vz, g.T)]
+    f = grids.perturb(base, seed=seed)
+    band = np.zeros(g.shape, bool)
+    band[g.dimx // 3: 2 * g.dimx // 3] = True
+    for v in range(3):
+        f[v] = np.where(band, (f[v].astype(np.float64) * scale).astype(dtype), f[v])
+    f[0][g.dimx // 3 + 1] = 0          # a plane of exact zeros inside the band
+    return f
+
+
+@pytest.mark.parametrize("core", [0, 1])
+@pytest.mark.parametrize("scale", [1e-20, 1e-29, 1e-33, 1e-38, 3e-42])
+@pytest.mark.parametrize("d", [0, 1, 2])
+def test_division_core_and_its_fallback(built, d, scale, core):
+    """fp32 pipe kernel: the scaling-free division core gives the IEEE quotient for plain operands; bundles that
+    meet an operand below 2^-100 (or a denormal) are computed again with full divisions.  Both against the oracle."""
+    O = _oracle()
+    dtype = np.float32
+    g = grids.box_with_obstacle(70, 66, 72, h=0.02)
+    params = capi.fluid_params(dtype, *PARAMS)
+    s = capi.Solver(g, params, dtype)
+    s.set_option(capi.OPT_SWEEP_KERNEL, capi.SWEEP_PIPE)
+    s.set_option(capi.OPT_DIV_CORE, core)
+    o = O.Oracle(g, params, dtype)
+    cur, tmp = _scaled_state(g, dtype, scale, 11), _scaled_state(g, dtype, scale, 12)
+    s.upload_layer(capi.LAYER_CUR, cur); s.upload_layer(capi.LAYER_TEMP, tmp)
+    for v in range(4):
+        o.set_field(O.L_CUR, v, cur[v]); o.set_field(O.L_TEMP, v, tmp[v])
+    for _ in range(2):      # the second sweep works on the merged temp of the first
+        s.sweep(d, DT, capi.LAYER_CUR, capi.LAYER_TEMP, capi.LAYER_NEXT, merge=True)
+        o.sweep(d, DT, O.L_CUR, O.L_TEMP, O.L_NEXT); o.merge(O.L_NEXT, O.L_TEMP)
+    assert_layers_equal(s, o, capi.LAYER_NEXT, O.L_NEXT, "next (scale %g, core %d)" % (scale, core))
+    assert_layers_equal(s, o, capi.LAYER_TEMP, O.L_TEMP, "merged temp")
+
+
+@pytest.mark.parametrize("dims,d", [((160, 12, 70), 0), ((12, 160, 70), 1), ((10, 70, 160), 2)])
+def test_division_core_long_lines(built, dims, d):
+    """Same as above for the 32-cells-per-wave instance (lines longer than 128 cells)."""
+    O = _oracle()
+    dtype = np.float32
+    g = grids.box(*dims, h=0.02)
+    params = capi.fluid_params(dtype, *PARAMS)
+    s = capi.Solver(g, params, dtype)
+    s.set_option(capi.OPT_SWEEP_KERNEL, capi.SWEEP_PIPE)
+    o = O.Oracle(g, params, dtype)
+    cur, tmp = _scaled_state(g, dtype, 1e-34, 21), _scaled_state(g, dtype, 1e-34, 22)
+    s.upload_layer(capi.LAYER_CUR, cur); s.upload_layer(capi.LAYER_TEMP, tmp)
+    for v in range(4):
+        o.set_field(O.L_CUR, v, cur[v]); o.set_field(O.L_TEMP, v, tmp[v])
+    s.sweep(d, DT, capi.LAYER_CUR, capi.LAYER_TEMP, capi.LAYER_NEXT, merge=True)
+    o.sweep(d, DT, O.L_CUR, O.L_TEMP, O.L_NEXT); o.merge(O.L_NEXT, O.L_TEMP)
+    assert_layers_equal(s, o, capi.LAYER_NEXT, O.L_NEXT, "next")
+    assert_layers_equal(s, o, capi.LAYER_TEMP, O.L_TEMP, "merged temp")

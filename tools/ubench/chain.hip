@@ -5,6 +5,7 @@
 #include <vector>
 
 #define CH 32
+__device__ __forceinline__ bool good(float v) { return ((__builtin_bit_cast(unsigned, v) << 1) - 2u) >= (2u * (27u << 23) - 2u); }   // 0 or |v| >= 2^-100
 template <int MODE, int ACTIVE>
 __global__ void __launch_bounds__(512, 2) k(const float *in, float *out, unsigned long long *cyc, float vis, float bb)
 {
@@ -19,6 +20,7 @@ __global__ void __launch_bounds__(512, 2) k(const float *in, float *out, unsigne
     }
     __syncthreads();
     float cp = 0.f, dp = 0.f;
+    bool ok = true;
     unsigned long long t0 = 0, t1 = 0;
     if (w < ACTIVE) {
         t0 = __builtin_amdgcn_s_memtime();
@@ -28,7 +30,17 @@ __global__ void __launch_bounds__(512, 2) k(const float *in, float *out, unsigne
             const float dd = MODE == 2 ? lds[(w * CH + t) * 64 + lane] : d[t];
             const float den = bb - a * cp;
             const float num = dd - dp * a;
-            if (MODE == 1) {            // reciprocal-multiply (NOT exact; lower bound of the chain latency)
+            if (MODE == 3) {            // shared refined reciprocal + two corrections per quotient (IEEE result when nothing needs scaling)
+                float r = __builtin_amdgcn_rcpf(den);
+                const float e = __builtin_fmaf(-den, r, 1.0f);
+                r = __builtin_fmaf(e, r, r);
+                float qc = c * r, qd = num * r;
+                float rc = __builtin_fmaf(-den, qc, c), rd = __builtin_fmaf(-den, qd, num);
+                qc = __builtin_fmaf(rc, r, qc); qd = __builtin_fmaf(rd, r, qd);
+                rc = __builtin_fmaf(-den, qc, c); rd = __builtin_fmaf(-den, qd, num);
+                cp = __builtin_fmaf(rc, r, qc); dp = __builtin_fmaf(rd, r, qd);
+                ok = ok & good(den) & good(c) & good(num);
+            } else if (MODE == 1) {            // reciprocal-multiply (NOT exact; lower bound of the chain latency)
                 const float r = __builtin_amdgcn_rcpf(den);
                 cp = c * r; dp = num * r;
             } else {
@@ -41,7 +53,7 @@ __global__ void __launch_bounds__(512, 2) k(const float *in, float *out, unsigne
         t1 = __builtin_amdgcn_s_memtime();
     }
     __syncthreads();
-    float s = 0;
+    float s = ok ? 0.f : 1.f;
 #pragma unroll
     for (int t = 0; t < CH; t++) s += q[t] + (MODE == 2 ? lds[(w * CH + t) * 64 + lane] : d[t]);
     out[blockIdx.x * 512 + threadIdx.x] = s;
@@ -76,6 +88,8 @@ int main()
     run<0, 8>("IEEE div, registers", in, out, cyc, blocks);
     run<1, 1>("rcp*mul (inexact), registers", in, out, cyc, blocks);
     run<1, 8>("rcp*mul (inexact), registers", in, out, cyc, blocks);
+    run<3, 1>("fast exact + guard, registers", in, out, cyc, blocks);
+    run<3, 8>("fast exact + guard, registers", in, out, cyc, blocks);
     run<2, 1>("IEEE div, d in LDS", in, out, cyc, blocks);
     run<2, 4>("IEEE div, d in LDS", in, out, cyc, blocks);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
