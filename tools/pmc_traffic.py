@@ -12,7 +12,7 @@ def load(path, name):
     return agg
 f = load(sys.argv[1], "FETCH_SIZE"); w = load(sys.argv[2], "WRITE_SIZE")
 cells = float(sys.argv[3]) if len(sys.argv) > 3 else 256.0**3
-print("%-44s %6s %14s %14s %12s %12s" % ("kernel", "calls", "fetch KiB/launch", "write KiB/launch", "B/cell raw", "B/cell corr"))
+print("%-52s %6s %14s %14s %12s %12s" % ("kernel", "calls", "fetch KiB/launch", "write KiB/launch", "B/cell raw", "B/cell corr"))
 for k in sorted(f):
     fk = sum(f[k]) / len(f[k]); wk = sum(w.get(k, [0])) / max(1, len(w.get(k, [0])))
-    print("%-44s %6d %14.0f %14.0f %12.1f %12.1f" % (k[:44], len(f[k]), fk, wk, (fk + wk) * 1024 / cells, (2 * fk + wk) * 1024 / cells))
+    print("%-52s %6d %14.0f %14.0f %12.1f %12.1f" % (k[:52], len(f[k]), fk, wk, (fk + wk) * 1024 / cells, (2 * fk + wk) * 1024 / cells))
