@@ -50,6 +50,10 @@ struct SweepParams {
     R dt;
     R v_T, t_phi;
     unsigned long long *stamps; // measurement only: per-wave phase time stamps (s_memtime), or nullptr
+    // x-slab halves of the X sweep (kernels_line.hip k_xsweep_*, kernels_pipe.hip MODE 1/2); null/0 otherwise
+    const R *carry_in; R *carry_out; const R *xcarry_in; R *xcarry_out;
+    int ghost_lo, ghost_hi;     // a neighbouring slab's plane stands before / behind the owned planes (X sweep stencils may read it)
+    int bundle0;                // first bundle of this launch (line block of the cross-slab pipeline)
     int fast_div;               // pipe kernel, fp32: constant divisors are in the range of the division core (kernels_pipe.hip)
     int merge;                  // 0: write next only; 1: also temp_out = merged; 2: merged twice (sweep merge + global merge)
 };
@@ -109,5 +113,8 @@ struct fs3d_ctx {
 // kernels_*.hip
 template <typename R> void launch_sweep_line(fs3d_ctx *c, int dir, const SweepParams<R> &p);
 template <typename R> bool launch_sweep_pipe(fs3d_ctx *c, int dir, const SweepParams<R> &p); // false: dims unsupported
+// X sweep halves of an x-slab for the bundles [b0, b1) (64 lines each, line = j*dimz + k); false: dims unsupported
+template <typename R> bool xslab_pipe_supported(const SweepParams<R> &p);
+template <typename R> bool launch_xslab_pipe(fs3d_ctx *c, SweepParams<R> p, int half, int b0, int b1);
 template <typename R> void launch_xsweep_fwd(fs3d_ctx *c, const SweepParams<R> &p, const void *carry_in, void *carry_out, long long l0, long long l1);
 template <typename R> void launch_xsweep_bwd(fs3d_ctx *c, const SweepParams<R> &p, const void *xcarry_in, void *xcarry_out, long long l0, long long l1);

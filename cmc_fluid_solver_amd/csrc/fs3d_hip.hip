@@ -493,6 +493,8 @@ static void fill_params(fs3d_ctx *c, SweepParams<R> &p, int dir, double dt_, int
     p.dt = dt; p.v_T = (R)c->v_T; p.t_phi = (R)c->t_phi;
     p.merge = merge;
     p.stamps = nullptr;
+    p.carry_in = nullptr; p.carry_out = nullptr; p.xcarry_in = nullptr; p.xcarry_out = nullptr; p.bundle0 = 0;
+    p.ghost_lo = c->x_offset > 0; p.ghost_hi = c->x_offset + c->dimx < c->dimx_global;
     // division core (fp32 pipe kernel): the constant divisors must be plain numbers in [2^-30, 2^60)
     auto plain = [](double v) { v = v < 0 ? -v : v; return v >= 9.313225746154785e-10 && v < 1.152921504606847e18; };
     p.fast_div = c->opt_div_core && plain((double)p.two_ds[0]) && plain((double)p.two_ds[1]) && plain((double)p.two_ds[2]) && plain((double)p.dt);
@@ -522,22 +524,29 @@ static fs3d_status xsweep_multi(fs3d_ctx *c, SweepParams<R> &p)
     }
     const bool first = c->rank == 0, last = c->rank == c->nranks - 1;
     const int nb = c->xblocks < 1 ? 1 : c->xblocks;
+    // per-slab halves: the pipe kernel (rows on chip, 64 lines per bundle) where the slab allows it, else thread-per-line
+    const bool pipe = c->opt_kernel != FS3D_SWEEP_LINE && xslab_pipe_supported<R>(p);
+    if (c->opt_kernel == FS3D_SWEEP_PIPE && !pipe) return fail(c, FS3D_ERR_UNSUPPORTED, "pipe kernel: slab dims unsupported for the X sweep");
     auto range = [&](int b, long long &l0, long long &l1) {
-        const long long per = ((long long)pl / 64 + nb - 1) / nb * 64;      // whole waves per block
+        const long long per = ((long long)pl / 64 + nb - 1) / nb * 64;      // whole waves / bundles per block
         l0 = std::min<long long>((long long)b * per, (long long)pl); l1 = std::min<long long>(l0 + per, (long long)pl);
     };
+    p.carry_in = first ? nullptr : (const R *)c->carry[0]; p.carry_out = (R *)c->carry[1];
+    p.xcarry_in = last ? nullptr : (const R *)c->carry[2]; p.xcarry_out = (R *)c->carry[3];
     for (int b = 0; b < nb; b++) {
         long long l0, l1; range(b, l0, l1);
         if (l1 <= l0) continue;
         if (!first && (st = fs3d_comm_xfer_rows(c, c->carry[0], 6, pl, l0, l1, c->rank - 1, false))) return st;
-        launch_xsweep_fwd<R>(c, p, first ? nullptr : c->carry[0], c->carry[1], l0, l1);
+        if (pipe) { if (!launch_xslab_pipe<R>(c, p, 1, (int)(l0 / 64), (int)(l1 / 64))) return fail(c, FS3D_ERR_HIP, "pipe kernel launch (forward half)"); }
+        else launch_xsweep_fwd<R>(c, p, first ? nullptr : c->carry[0], c->carry[1], l0, l1);
         if (!last && (st = fs3d_comm_xfer_rows(c, c->carry[1], 6, pl, l0, l1, c->rank + 1, true))) return st;
     }
     for (int b = 0; b < nb; b++) {
         long long l0, l1; range(b, l0, l1);
         if (l1 <= l0) continue;
         if (!last && (st = fs3d_comm_xfer_rows(c, c->carry[2], 4, pl, l0, l1, c->rank + 1, false))) return st;
-        launch_xsweep_bwd<R>(c, p, last ? nullptr : c->carry[2], c->carry[3], l0, l1);
+        if (pipe) { if (!launch_xslab_pipe<R>(c, p, 2, (int)(l0 / 64), (int)(l1 / 64))) return fail(c, FS3D_ERR_HIP, "pipe kernel launch (backward half)"); }
+        else launch_xsweep_bwd<R>(c, p, last ? nullptr : c->carry[2], c->carry[3], l0, l1);
         if (!first && (st = fs3d_comm_xfer_rows(c, c->carry[3], 4, pl, l0, l1, c->rank - 1, true))) return st;
     }
     return FS3D_OK;

@@ -153,6 +153,7 @@ struct Chunk {
     static constexpr int TILE_ELEMS = 66 * TSTRIDE;    // 64 lines + the line below + the line above
 
     int n, s0, lane;
+    int slo, shi;              // clamp range of the cell index along the sweep: [0, n-1], or one more where a ghost plane of a neighbouring slab stands
     bool lane_valid;
     unsigned row0;             // byte offset (inside a field incl. its leading halo plane) of (lane 0, cell 0)
     unsigned ssb;              // byte stride along the sweep
@@ -175,6 +176,14 @@ struct Chunk {
     {
         int s = s0 + t;
         s = s < 0 ? 0 : (s > n - 1 ? n - 1 : s);
+        return row0 + (unsigned)s * ssb;
+    }
+    // the same for the two sweep-halo cells of a layer field: where a neighbouring slab's ghost plane stands before /
+    // behind the owned planes the index may leave [0, n-1] by one (layer fields only: they carry halo planes)
+    __device__ __forceinline__ unsigned soff_halo(int t) const
+    {
+        int s = s0 + t;
+        s = s < slo ? slo : (s > shi ? shi : s);
         return row0 + (unsigned)s * ssb;
     }
     __device__ __forceinline__ bool cell_ok(int t) const { return s0 + t < n; }
@@ -208,11 +217,11 @@ struct Chunk {
             }
         } else {
 #pragma unroll
-            for (int t = 0; t < PC; t++) r.v[t] = Buf<R>::ld(f, vob, soff(c0 + t) + dub);
+            for (int t = 0; t < PC; t++) r.v[t] = Buf<R>::ld(f, vob, soff_halo(c0 + t) + dub);   // cell n of a slab may be a neighbour's ghost plane
         }
         if (HALO) {
-            r.lo = Buf<R>::ld(f, vob, soff(c0 - 1) + dub);
-            r.hi = Buf<R>::ld(f, vob, soff(c0 + PC) + dub);
+            r.lo = Buf<R>::ld(f, vob, soff_halo(c0 - 1) + dub);
+            r.hi = Buf<R>::ld(f, vob, soff_halo(c0 + PC) + dub);
         }
     }
     template <bool EDGES>
@@ -320,7 +329,11 @@ struct Chunk {
 // FM (fp32 only): divide with the scaling-free core; a workgroup that met an operand outside the core's range
 // raises redo[bundle] and the FM = false instance, launched right behind with the same arguments, computes that
 // bundle again with full divisions (every other workgroup of it returns at once).
-template <typename R, int DIR, int CH, bool FM>
+// MODE (X sweep of an x-slab, SS6 of DESIGN.md): 0 whole sweep; 1 forward half -- the recurrences start from the
+// carries of the slab below (p.carry_in) and the eliminated rows go to the HBM scratch, carries of the last cell to
+// p.carry_out; 2 backward half -- rows from the scratch, x of the slab above (p.xcarry_in), then the O phase.
+// Same operations on the same values as the whole sweep: a line cut into slabs gives the uncut line's numbers.
+template <typename R, int DIR, int CH, bool FM, int MODE = 0>
 __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p, int n_o, int n_tiles, int *redo)
 {
     if (!FM && redo && redo[blockIdx.x] == 0) return;      // redo pass: this bundle was fine
@@ -338,7 +351,10 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
         const int q = nb >> 3, r = nb & 7, x = lb & 7, slot = lb >> 3;
         lb = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + slot;
     }
-    const int tile_id = lb / n_o, o = lb - tile_id * n_o;   // tile-major: consecutive ids = consecutive planes
+    // tile-major: consecutive ids = consecutive planes.  Slab halves: row-major from p.bundle0 on, so that a block of
+    // bundles is a contiguous range of lines in the carry arrays (line = j*dimz + k, 64 per bundle).
+    if (MODE != 0) lb += p.bundle0;
+    const int tile_id = MODE != 0 ? lb % n_tiles : lb / n_o, o = MODE != 0 ? lb / n_tiles : lb - tile_id * n_o;
 
     const int n = DIR == 0 ? p.dimx : (DIR == 1 ? p.dimy : p.dimz);
     const int la_len = DIR == 2 ? p.dimy : p.dimz;          // length of the lane axis
@@ -374,6 +390,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
 
     Chunk<R, DIR, CH> ck;
     ck.n = n; ck.s0 = w * CH; ck.lane = lane; ck.lane_valid = l < la_len;
+    ck.slo = (DIR == 0 && p.ghost_lo) ? -1 : 0; ck.shi = (DIR == 0 && p.ghost_hi) ? n : n - 1;
     {
         // wave-uniform element offset of (lane 0, cell 0) from the first owned cell, then + the halo plane
         const long long ub = DIR == 0 ? (long long)o * p.dimz + tile_id * 64
@@ -616,13 +633,18 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
             }
             __builtin_amdgcn_sched_barrier(0);
         };
-        static_for<CK::NPASS>([&](auto pass_c) __attribute__((always_inline)) {
-            constexpr int c0 = decltype(pass_c)::value * PC;
-            constexpr unsigned PCM = PC >= 32 ? 0xFFFFFFFFu : ((1u << PC) - 1u);
-            p_pass(c0);                                              // INTERIOR rows for every cell
-            if (((umask >> c0) & PCM) != PCM) p_fix(c0);            // wave-uniform: some line has another row kind here
-        });
+        if (MODE != 2) {
+            static_for<CK::NPASS>([&](auto pass_c) __attribute__((always_inline)) {
+                constexpr int c0 = decltype(pass_c)::value * PC;
+                constexpr unsigned PCM = PC >= 32 ? 0xFFFFFFFFu : ((1u << PC) - 1u);
+                p_pass(c0);                                              // INTERIOR rows for every cell
+                if (((umask >> c0) & PCM) != PCM) p_fix(c0);            // wave-uniform: some line has another row kind here
+            });
+        }
     }
+    // slab halves: the eliminated rows travel through the HBM scratch (6 arrays without halo planes, like the node values)
+    const rsrc_t rScr = __builtin_amdgcn_make_buffer_rsrc((void *)(p.scr_ - p.plane), 0, (int)(5u * nsb + ck.fbytes), 0x00020000);
+    const long long cline = (long long)o * p.dimz + l;      // this lane's line in the carry arrays [value][line] (X sweep)
 
     // ------------------------------------------------------------------ F: forward relays, staggered
     // The four right-hand sides (T, U, V, W) are four independent first-order recurrences once each pass
@@ -646,6 +668,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
     for (int o = 0; o < CH; o += 8) { SPLIT8(st0, o); SPLIT8(st1, o); SPLIT8(st2, o); SPLIT8(st3, o); }
     STAMP(1);
     __builtin_amdgcn_s_setprio(3);     // the serial chains are latency-critical: ahead of other waves' P/O work
+    if (MODE != 2) {
     if (w > 0) flag_wait(&fflag[3 * PIPE_NW + w - 1]);
     STAMP(2);
 #define FWD_COEF(VAR, FASTC)                                                                              \
@@ -670,6 +693,10 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
         if (w > 0) {                                                                                      \
             flag_wait(&fflag[VAR * PIPE_NW + w - 1]);                                                     \
             cp = relay[(2 * VAR) * 64 + lane]; dp = relay[(2 * VAR + 1) * 64 + lane];                     \
+        } else if (MODE == 1 && p.carry_in && lane_valid) {                                               \
+            /* the recurrence continues the slab below (k_xsweep_fwd's carry layout) */                  \
+            cp = p.carry_in[(VAR == 3 ? 1 : 0) * p.plane + cline];                                        \
+            dp = p.carry_in[(2 + VAR) * p.plane + cline];                                                 \
         }                                                                                                 \
         R vis = VAR == 3 ? p.vis_t : p.vis_v, bb = VAR == 3 ? p.b_t : p.b_v;                              \
         /* opaque per pass: otherwise U computes every a, c once and parks them in scratch for V and W */ \
@@ -708,6 +735,42 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
     if (FM) { if (!__all(ok.plain()) && lane == 0) atomicOr(&redo[blockIdx.x], 1); }
 #undef FWD_COEF
     STAMP(3);
+    }   // MODE != 2
+    if (MODE == 1) {
+        // forward half of a slab: rows to the scratch, the carries of the slab's last cell to the next rank
+#pragma unroll
+        for (int t = 0; t < CH; t++) {
+            const unsigned vo = ck.cell_ok(t) ? ck.vob_st : BUF_OOB;
+            const unsigned so_ = ck.soff(t);
+            Buf<R>::st(rScr, vo, so_, st0[t]);            Buf<R>::st(rScr, vo, so_ + nsb, myC[t * 64]);
+            Buf<R>::st(rScr, vo, so_ + 2 * nsb, st1[t]);  Buf<R>::st(rScr, vo, so_ + 3 * nsb, st2[t]);
+            Buf<R>::st(rScr, vo, so_ + 4 * nsb, st3[t]);  Buf<R>::st(rScr, vo, so_ + 5 * nsb, myD[t * 64]);
+        }
+        const int wl = (n - 1) / CH, tl = (n - 1) - wl * CH;
+        if (w == wl && lane_valid) {
+            R cv = R(0), d0 = R(0), d1 = R(0), d2 = R(0);
+#pragma unroll
+            for (int t = 0; t < CH; t++) if (t == tl) { cv = st0[t]; d0 = st1[t]; d1 = st2[t]; d2 = st3[t]; }
+            p.carry_out[0 * p.plane + cline] = cv;  p.carry_out[1 * p.plane + cline] = myC[tl * 64];
+            p.carry_out[2 * p.plane + cline] = d0;  p.carry_out[3 * p.plane + cline] = d1;
+            p.carry_out[4 * p.plane + cline] = d2;  p.carry_out[5 * p.plane + cline] = myD[tl * 64];
+        }
+        return;
+    }
+    if (MODE == 2) {
+        // backward half: rows back from the scratch.  Cells past the slab get c' = -1, d' = 0: x passes through them.
+#pragma unroll
+        for (int t = 0; t < CH; t++) {
+            const unsigned so_ = ck.soff(t);
+            const bool in = ck.cell_ok(t);
+            const R a0 = Buf<R>::ld(rScr, ck.vob, so_), a1 = Buf<R>::ld(rScr, ck.vob, so_ + nsb);
+            const R a2 = Buf<R>::ld(rScr, ck.vob, so_ + 2 * nsb), a3 = Buf<R>::ld(rScr, ck.vob, so_ + 3 * nsb);
+            const R a4 = Buf<R>::ld(rScr, ck.vob, so_ + 4 * nsb), a5 = Buf<R>::ld(rScr, ck.vob, so_ + 5 * nsb);
+            st0[t] = in ? a0 : R(-1); myC[t * 64] = in ? a1 : R(-1);
+            st1[t] = in ? a2 : R(0); st2[t] = in ? a3 : R(0); st3[t] = in ? a4 : R(0); myD[t * 64] = in ? a5 : R(0);
+            if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
 
     // ------------------------------------------------------------------ B: backward relay (registers/LDS only)
     // The last wave finishes its last forward pass after every other wave has finished all of theirs (each pass
@@ -719,6 +782,10 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
         if (w < PIPE_NW - 1) {
             x[0] = relay[0 * 64 + lane]; x[1] = relay[1 * 64 + lane];
             x[2] = relay[2 * 64 + lane]; x[3] = relay[3 * 64 + lane];
+        } else if (MODE == 2 && p.xcarry_in && lane_valid) {
+            // x of the first cell of the slab above (k_xsweep_bwd's carry layout)
+            x[0] = p.xcarry_in[0 * p.plane + cline]; x[1] = p.xcarry_in[1 * p.plane + cline];
+            x[2] = p.xcarry_in[2 * p.plane + cline]; x[3] = p.xcarry_in[3 * p.plane + cline];
         }
 #pragma unroll
         for (int t = CH - 1; t >= 0; t--) {
@@ -733,6 +800,10 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
         relay[0 * 64 + lane] = x[0]; relay[1 * 64 + lane] = x[1];
         relay[2 * 64 + lane] = x[2]; relay[3 * 64 + lane] = x[3];
         flag_set(&bflag[w]);
+        if (MODE == 2 && w == 0 && p.xcarry_out && lane_valid) {
+            p.xcarry_out[0 * p.plane + cline] = x[0]; p.xcarry_out[1 * p.plane + cline] = x[1];
+            p.xcarry_out[2 * p.plane + cline] = x[2]; p.xcarry_out[3 * p.plane + cline] = x[3];
+        }
     }
     __builtin_amdgcn_s_setprio(0);
     STAMP(5);
@@ -875,4 +946,59 @@ bool launch_sweep_pipe<double>(fs3d_ctx *c, int dir, const SweepParams<double> &
     if ((unsigned long long)p.fstride * 4ull * sizeof(double) >= (1ull << 32)) return false;
     if (n <= PIPE_NW * 16) return launch_dir<double, 16>(c, dir, p);
     return false;
+}
+
+// ---- X sweep halves of an x-slab (cross-slab pipeline, fs3d_hip.hip: xsweep_multi) -------------------------
+template <typename R, int CH>
+static bool launch_xslab(fs3d_ctx *c, SweepParams<R> p, int half, int b0, int b1)
+{
+    constexpr bool HAS_FM = std::is_same<R, float>::value;
+    const int n_o = p.dimy, n_tiles = p.dimz / 64, grid = b1 - b0;
+    const size_t tile = Chunk<R, 0, CH>::TILE_ELEMS;
+    const size_t lds_c = (size_t)PIPE_NW * CH * 64 + (tile <= (size_t)CH * 64 ? 0 : (size_t)PIPE_NW * tile);
+    const size_t lds = ((size_t)PIPE_NW * CH * 64 + lds_c + 8 * 64) * sizeof(R) + 5 * PIPE_NW * sizeof(int);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)k_sweep_pipe<R, 0, CH, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+        if (hipFuncSetAttribute((const void *)k_sweep_pipe<R, 0, CH, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+        if (HAS_FM && hipFuncSetAttribute((const void *)k_sweep_pipe<R, 0, CH, HAS_FM, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+        attr_set = true;
+    }
+    if (grid <= 0) return true;
+    p.bundle0 = b0;
+    if (half == 1) {
+        if (HAS_FM && p.fast_div) {
+            if (c->redo_cap < grid) {
+                if (c->redo) { hipStreamSynchronize(c->stream); hipFree(c->redo); c->redo = nullptr; c->redo_cap = 0; }
+                const int cap = std::max(grid, n_o * n_tiles);
+                if (hipMalloc(&c->redo, (size_t)cap * sizeof(int)) != hipSuccess) return false;
+                if (hipMemsetAsync(c->redo, 0, (size_t)cap * sizeof(int), c->stream) != hipSuccess) return false;
+                c->redo_cap = cap;
+            }
+            hipLaunchKernelGGL((k_sweep_pipe<R, 0, CH, HAS_FM, 1>), dim3((unsigned)grid), dim3(PIPE_NW * 64), lds, c->stream, p, n_o, n_tiles, c->redo);
+            hipLaunchKernelGGL((k_sweep_pipe<R, 0, CH, false, 1>), dim3((unsigned)grid), dim3(PIPE_NW * 64), lds, c->stream, p, n_o, n_tiles, c->redo);
+        } else {
+            hipLaunchKernelGGL((k_sweep_pipe<R, 0, CH, false, 1>), dim3((unsigned)grid), dim3(PIPE_NW * 64), lds, c->stream, p, n_o, n_tiles, (int *)nullptr);
+        }
+    } else {
+        hipLaunchKernelGGL((k_sweep_pipe<R, 0, CH, false, 2>), dim3((unsigned)grid), dim3(PIPE_NW * 64), lds, c->stream, p, n_o, n_tiles, (int *)nullptr);
+    }
+    return true;
+}
+
+template <> bool xslab_pipe_supported<float>(const SweepParams<float> &p)
+{
+    return p.dimz % 64 == 0 && p.dimx <= PIPE_NW * 32 && (unsigned long long)p.fstride * 4ull * sizeof(float) < (1ull << 32);
+}
+template <> bool xslab_pipe_supported<double>(const SweepParams<double> &p)
+{
+    return p.dimz % 64 == 0 && p.dimx <= PIPE_NW * 16 && (unsigned long long)p.fstride * 4ull * sizeof(double) < (1ull << 32);
+}
+template <> bool launch_xslab_pipe<float>(fs3d_ctx *c, SweepParams<float> p, int half, int b0, int b1)
+{
+    return p.dimx <= PIPE_NW * 16 ? launch_xslab<float, 16>(c, p, half, b0, b1) : launch_xslab<float, 32>(c, p, half, b0, b1);
+}
+template <> bool launch_xslab_pipe<double>(fs3d_ctx *c, SweepParams<double> p, int half, int b0, int b1)
+{
+    return launch_xslab<double, 16>(c, p, half, b0, b1);
 }

@@ -112,3 +112,65 @@ def test_slab_kernel_level_calls():
     for r in range(nranks):
         assert res[r][1][1] == ref_err[1]
         np.testing.assert_allclose(res[r][1][0], ref_err[0], rtol=1e-12)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("nranks,xblocks", [(2, 1), (3, 4), (4, 3)])
+def test_pipe_kernel_halves_across_slabs(dtype, nranks, xblocks, monkeypatch):
+    """dimz a multiple of 64: the X sweep of each slab runs as the forward / backward half of the pipe kernel
+    (rows through the HBM scratch, carries between the ranks) -- forced with FS3D_SWEEP_PIPE so that a silent
+    fall-back to the thread-per-line halves would fail.  Lines of 50 cells cut into uneven slabs, an obstacle
+    (two segments per line, segment ends inside slabs), tiny values in part of the state (division core + redo)."""
+    monkeypatch.setenv("FS3D_XBLOCKS", str(xblocks))
+    g = grids.box_with_obstacle(50, 20, 64, h=0.03)
+    params = capi.fluid_params(dtype, *PARAMS)
+    s = capi.Solver(g, params, dtype)
+    s.UpdateBoundaries()
+    ref_err = [s.TimeStep(DT, 2, 2, True) for _ in range(3)]
+    ref = s.download_layer(capi.LAYER_CUR)
+    s.close()
+
+    grp = capi.LocalGroup(g, params, nranks, dtype)
+    for sv in grp.solvers:
+        sv.set_option(capi.OPT_SWEEP_KERNEL, capi.SWEEP_PIPE)
+
+    def work(rank, sv):
+        sv.UpdateBoundaries()
+        errs = [sv.TimeStep(DT, 2, 2, True) for _ in range(3)]
+        return sv.download_layer(capi.LAYER_CUR), errs
+    res = grp.run(work)
+    grp.close()
+    for v in range(4):
+        got = np.concatenate([res[r][0][v] for r in range(nranks)], axis=0)
+        assert np.array_equal(ref[v], got), "field %d" % v
+    np.testing.assert_allclose(res[0][1], ref_err, rtol=1e-12)
+
+
+def test_pipe_kernel_halves_long_slabs():
+    """Slabs of 100 planes: the 32-cells-per-wave instance of the halves, relay over several waves per slab."""
+    dtype = np.float32
+    g = grids.box(200, 8, 64, h=0.02)
+    params = capi.fluid_params(dtype, *PARAMS)
+    base = [np.ascontiguousarray(a, dtype) for a in (g.vx, g.vy, g.vz, g.T)]
+    cur, tmp = grids.perturb(base, seed=5), grids.perturb(base, seed=6)
+    s = capi.Solver(g, params, dtype)
+    s.upload_layer(capi.LAYER_CUR, cur); s.upload_layer(capi.LAYER_TEMP, tmp)
+    s.sweep(capi.DIR_X, DT, capi.LAYER_CUR, capi.LAYER_TEMP, capi.LAYER_NEXT, merge=True)
+    ref_next, ref_tmp = s.download_layer(capi.LAYER_NEXT), s.download_layer(capi.LAYER_TEMP)
+    s.close()
+    nranks = 2
+    grp = capi.LocalGroup(g, params, nranks, dtype)
+    for sv in grp.solvers:
+        sv.set_option(capi.OPT_SWEEP_KERNEL, capi.SWEEP_PIPE)
+
+    def work(rank, sv):
+        x0, x1 = slab_range(g.dimx, rank, nranks)
+        sv.upload_layer(capi.LAYER_CUR, [a[x0:x1] for a in cur])
+        sv.upload_layer(capi.LAYER_TEMP, [a[x0:x1] for a in tmp])
+        sv.sweep(capi.DIR_X, DT, capi.LAYER_CUR, capi.LAYER_TEMP, capi.LAYER_NEXT, merge=True)
+        return sv.download_layer(capi.LAYER_NEXT), sv.download_layer(capi.LAYER_TEMP)
+    res = grp.run(work)
+    grp.close()
+    for v in range(4):
+        assert np.array_equal(ref_next[v], np.concatenate([res[r][0][v] for r in range(nranks)], axis=0)), "next %d" % v
+        assert np.array_equal(ref_tmp[v], np.concatenate([res[r][1][v] for r in range(nranks)], axis=0)), "temp %d" % v
