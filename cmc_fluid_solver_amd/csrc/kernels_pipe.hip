@@ -152,7 +152,8 @@ struct Chunk {
     static constexpr int TSTRIDE = PC + 1;             // padded LDS row (conflict-free column access)
     static constexpr int TILE_ELEMS = 66 * TSTRIDE;    // 64 lines + the line below + the line above
 
-    int n, s0, lane;
+    int n, lane;
+    int wpc;                   // w * PC: first cell of this wave's first piece
     int slo, shi;              // clamp range of the cell index along the sweep: [0, n-1], or one more where a ghost plane of a neighbouring slab stands
     bool lane_valid;
     unsigned row0;             // byte offset (inside a field incl. its leading halo plane) of (lane 0, cell 0)
@@ -171,22 +172,28 @@ struct Chunk {
     {
         return __builtin_amdgcn_make_buffer_rsrc((void *)(first_owned - plane), 0, (int)(4u * fsb), 0x00020000);
     }
-    // byte offset of cell s0+t of lane 0, cell index clamped into the line
-    __device__ __forceinline__ unsigned soff(int t) const
+    // The CH cells of a wave are CH/PC pieces of PC cells; piece h of wave w is cells [h*NW*PC + w*PC, +PC) of the
+    // line: consecutive pieces of the line belong to consecutive waves (wave 2m and 2m+1 share the 128-byte lines
+    // of a Z sweep and work on them in the same sub-pass), and the relays hand over every PC cells.
+    // Local cell index lt in [0, CH) -> piece lt / PC, position lt % PC.
+    __device__ __forceinline__ int base(int c0) const { return (c0 / PC) * (PIPE_NW * PC) + wpc; }   // c0: first local cell of a piece
+    __device__ __forceinline__ int cell(int lt) const { return base(lt - lt % PC) + lt % PC; }
+    // byte offset of local cell lt of lane 0, cell index clamped into the line
+    __device__ __forceinline__ unsigned soff(int lt) const
     {
-        int s = s0 + t;
+        int s = cell(lt);
         s = s < 0 ? 0 : (s > n - 1 ? n - 1 : s);
         return row0 + (unsigned)s * ssb;
     }
-    // the same for the two sweep-halo cells of a layer field: where a neighbouring slab's ghost plane stands before /
+    // cell base(c0) + dt of a layer field, dt in [-1, PC]: where a neighbouring slab's ghost plane stands before /
     // behind the owned planes the index may leave [0, n-1] by one (layer fields only: they carry halo planes)
-    __device__ __forceinline__ unsigned soff_halo(int t) const
+    __device__ __forceinline__ unsigned soff_halo(int c0, int dt) const
     {
-        int s = s0 + t;
+        int s = base(c0) + dt;
         s = s < slo ? slo : (s > shi ? shi : s);
         return row0 + (unsigned)s * ssb;
     }
-    __device__ __forceinline__ bool cell_ok(int t) const { return s0 + t < n; }
+    __device__ __forceinline__ bool cell_ok(int lt) const { return cell(lt) < n; }
 
     // One field of a sub-pass in flight: X/Y hold the PC values themselves, Z the raw 16-byte row pieces that
     // still have to go through the transposition tile.  `issue` only starts the loads, `land` delivers out[0..PC):
@@ -201,7 +208,7 @@ struct Chunk {
     {
         if (DIR == 2) {
             const int piece = lane % PR, rsub = lane / PR;
-            int pos = s0 + c0 + piece * VW;                 // first cell of this lane's 16-byte piece
+            int pos = base(c0) + piece * VW;                // first cell of this lane's 16-byte piece
             pos = pos > n - VW ? n - VW : pos;
 #pragma unroll
             for (int i = 0; i < PR; i++) {
@@ -217,11 +224,11 @@ struct Chunk {
             }
         } else {
 #pragma unroll
-            for (int t = 0; t < PC; t++) r.v[t] = Buf<R>::ld(f, vob, soff_halo(c0 + t) + dub);   // cell n of a slab may be a neighbour's ghost plane
+            for (int t = 0; t < PC; t++) r.v[t] = Buf<R>::ld(f, vob, soff_halo(c0, t) + dub);   // cell n of a slab may be a neighbour's ghost plane
         }
         if (HALO) {
-            r.lo = Buf<R>::ld(f, vob, soff_halo(c0 - 1) + dub);
-            r.hi = Buf<R>::ld(f, vob, soff_halo(c0 + PC) + dub);
+            r.lo = Buf<R>::ld(f, vob, soff_halo(c0, -1) + dub);
+            r.hi = Buf<R>::ld(f, vob, soff_halo(c0, PC) + dub);
         }
     }
     template <bool EDGES>
@@ -261,12 +268,6 @@ struct Chunk {
         __builtin_amdgcn_sched_barrier(0);   // every load of the field is in flight before the first consumer
         land<EDGES>(r, out);
     }
-    // the two cells just outside [c0, c0+PC) (clamped into the line)
-    __device__ __forceinline__ void load_halo(rsrc_t f, unsigned fo, int c0, R &lo, R &hi) const
-    {
-        lo = Buf<R>::ld(f, vob, soff(c0 - 1) + fo);
-        hi = Buf<R>::ld(f, vob, soff(c0 + PC) + fo);
-    }
     // one cell of this lane (any field-relative uniform byte offset)
     __device__ __forceinline__ R at(rsrc_t f, unsigned so) const { return Buf<R>::ld(f, vob, so); }
 
@@ -284,13 +285,13 @@ struct Chunk {
             R *const trow = tile + (rsub * TSTRIDE + col);
 #pragma unroll
             for (int t = 0; t < PC; t++) tcol[t] = in[t];
-            const bool col_ok = s0 + c0 + col < n;
+            const bool col_ok = base(c0) + col < n;
 #pragma unroll
             for (int r = 0; r < PC; r++) {
                 const int row = r * RPS + rsub;
                 const R val = trow[r * RPS * TSTRIDE];
                 const bool ok = col_ok && row < rows_valid;
-                Buf<R>::st(f, ok ? (unsigned)(row * dimz + s0 + c0 + col) * (unsigned)sizeof(R) : BUF_OOB, row0 + fo, val);
+                Buf<R>::st(f, ok ? (unsigned)(row * dimz + base(c0) + col) * (unsigned)sizeof(R) : BUF_OOB, row0 + fo, val);
             }
         } else {
 #pragma unroll
@@ -376,9 +377,10 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
     R *ldsD = (R *)smem_raw;
     R *ldsC = ldsD + LDS_D;
     R *relay = ldsC + LDS_C;                                // 8 x 64 forward (c', d' per pass), reused 4 x 64 backward
-    volatile int *fflag = (volatile int *)(relay + 8 * 64); // [4 passes][NW]: forward pass k of wave w is done
-    volatile int *bflag = fflag + 4 * PIPE_NW;              // [NW]: backward pass of wave w is done
-    if (threadIdx.x < 5 * PIPE_NW) fflag[threadIdx.x] = 0;
+    constexpr int NPIECE = Chunk<R, DIR, CH>::NPASS;        // pieces per wave; relay step (h, w) = piece h of wave w
+    volatile int *fflag = (volatile int *)(relay + 8 * 64); // [4 passes][NPIECE][NW]: forward pass k of step (h, w) is done
+    volatile int *bflag = fflag + 4 * NPIECE * PIPE_NW;     // [NPIECE][NW]: backward step (h, w) is done
+    if (threadIdx.x < 5 * NPIECE * PIPE_NW) fflag[threadIdx.x] = 0;
     __syncthreads();                                        // the only workgroup-wide barrier of the kernel
 #ifndef FS3D_NO_P_PRIO
     // The relay visits the waves in order, so the low waves are needed first: give them the issue slots first.
@@ -389,7 +391,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
 #endif
 
     Chunk<R, DIR, CH> ck;
-    ck.n = n; ck.s0 = w * CH; ck.lane = lane; ck.lane_valid = l < la_len;
+    ck.n = n; ck.wpc = w * Chunk<R, DIR, CH>::PC; ck.lane = lane; ck.lane_valid = l < la_len;
     ck.slo = (DIR == 0 && p.ghost_lo) ? -1 : 0; ck.shi = (DIR == 0 && p.ghost_hi) ? n : n - 1;
     {
         // wave-uniform element offset of (lane 0, cell 0) from the first owned cell, then + the halo plane
@@ -407,7 +409,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
     ck.dimz = p.dimz;
     ck.rows_valid = la_len - tile_id * 64 < 64 ? la_len - tile_id * 64 : 64;
     ck.tile = TILE_IN_ROWS ? ldsC + (size_t)w * CH * 64 : ldsC + (size_t)PIPE_NW * CH * 64 + (size_t)w * TILE;
-    const int s0 = ck.s0;
+    const int s0 = w * CH;                                      // first row of this wave in the LDS arrays (storage order, not line order)
     const bool lane_valid = ck.lane_valid;
     // this thread's column of the c'_T / d_T arrays: cell t of the chunk is at myX[t * 64] (immediate DS offsets)
     R *const myD = ldsD + ((size_t)s0 * 64 + lane);
@@ -444,10 +446,10 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
         for (int t = 0; t < CH; t++) {
             // unconditional load, then masked arithmetically (a select would be turned back into a branch)
             int cw = __builtin_amdgcn_raw_buffer_load_b16(rCode, ck.vob / (sizeof(R) / 2), ck.soff(t) / (sizeof(R) / 2), 0);
-            cw &= -(int)(lane_valid && s0 + t < n);
+            cw &= -(int)(lane_valid && ck.cell_ok(t));
             const int code = (cw >> (4 * DIR)) & 0xF;
             cpack[t >> 3] |= (unsigned)code << (4 * (t & 7));
-            if (((cw >> CODE_TYPE_SHIFT) & 3) == FS3D_NODE_IN && lane_valid && s0 + t < n) inmask |= 1u << t;
+            if (((cw >> CODE_TYPE_SHIFT) & 3) == FS3D_NODE_IN && lane_valid && ck.cell_ok(t)) inmask |= 1u << t;
             if ((code & 3) != ROW_SKIP) segmask |= 1u << t;
             if ((code & 3) == ROW_INTERIOR) intmask |= 1u << t;
         }
@@ -669,7 +671,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
     STAMP(1);
     __builtin_amdgcn_s_setprio(3);     // the serial chains are latency-critical: ahead of other waves' P/O work
     if (MODE != 2) {
-    if (w > 0) flag_wait(&fflag[3 * PIPE_NW + w - 1]);
+    if (w > 0) flag_wait(&fflag[3 * NPIECE * PIPE_NW + w - 1]);
     STAMP(2);
 #define FWD_COEF(VAR, FASTC)                                                                              \
     {                                                                                                     \
@@ -687,11 +689,12 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
             b4[i] = is_int ? bb : (fr ? R(2) : R(1));                                                     \
         }                                                                                                 \
     }
-#define FWD_PASS(VAR, DREAD, DWRITE, CWRITE)                                                              \
+#define FWD_PASS(VAR, H, DREAD, DWRITE, CWRITE)                                                           \
     {                                                                                                     \
+        /* step (H, w) follows (H, w-1), or (H-1, NW-1) for w = 0: the pieces in the order of the line */ \
         R cp = R(0), dp = R(0);                                                                           \
-        if (w > 0) {                                                                                      \
-            flag_wait(&fflag[VAR * PIPE_NW + w - 1]);                                                     \
+        if (w > 0 || H > 0) {                                                                             \
+            flag_wait(&fflag[(VAR * NPIECE + (w > 0 ? H : H - 1)) * PIPE_NW + (w > 0 ? w - 1 : PIPE_NW - 1)]); \
             cp = relay[(2 * VAR) * 64 + lane]; dp = relay[(2 * VAR + 1) * 64 + lane];                     \
         } else if (MODE == 1 && p.carry_in && lane_valid) {                                               \
             /* the recurrence continues the slab below (k_xsweep_fwd's carry layout) */                  \
@@ -701,7 +704,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
         R vis = VAR == 3 ? p.vis_t : p.vis_v, bb = VAR == 3 ? p.b_t : p.b_v;                              \
         /* opaque per pass: otherwise U computes every a, c once and parks them in scratch for V and W */ \
         asm volatile("" : "+s"(vis), "+s"(bb));                                                           \
-        _Pragma("unroll") for (int g = 0; g < CH; g += 4) {                                               \
+        _Pragma("unroll") for (int g = H * PC; g < (H + 1) * PC; g += 4) {                                \
             R a4[4], b4[4], c4[4];                                                                        \
             /* the group's q values become available only with the chain state of the previous group:   \
                otherwise the coefficients of the whole chunk are computed up front (96 live registers) */ \
@@ -725,12 +728,15 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
             __builtin_amdgcn_sched_barrier(0);                                                            \
         }                                                                                                 \
         relay[(2 * VAR) * 64 + lane] = cp; relay[(2 * VAR + 1) * 64 + lane] = dp;                         \
-        flag_set(&fflag[VAR * PIPE_NW + w]);                                                              \
+        flag_set(&fflag[(VAR * NPIECE + H) * PIPE_NW + w]);                                               \
     }
-    FWD_PASS(3, myD[t * 64], myD[t * 64] = dp, myC[t * 64] = cp)
-    FWD_PASS(0, st1[t], st1[t] = dp, (void)0)
-    FWD_PASS(1, st2[t], st2[t] = dp, (void)0)
-    FWD_PASS(2, st3[t], st3[t] = dp, st0[t] = cp)          // last pass over the cell: c'_uvw replaces q
+    static_for<NPIECE>([&](auto h_c) __attribute__((always_inline)) {
+        constexpr int H = decltype(h_c)::value;
+        FWD_PASS(3, H, myD[t * 64], myD[t * 64] = dp, myC[t * 64] = cp)
+        FWD_PASS(0, H, st1[t], st1[t] = dp, (void)0)
+        FWD_PASS(1, H, st2[t], st2[t] = dp, (void)0)
+        FWD_PASS(2, H, st3[t], st3[t] = dp, st0[t] = cp)       // last pass over the cell: c'_uvw replaces q
+    });
 #undef FWD_PASS
     if (FM) { if (!__all(ok.plain()) && lane == 0) atomicOr(&redo[blockIdx.x], 1); }
 #undef FWD_COEF
@@ -746,7 +752,8 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
             Buf<R>::st(rScr, vo, so_ + 2 * nsb, st1[t]);  Buf<R>::st(rScr, vo, so_ + 3 * nsb, st2[t]);
             Buf<R>::st(rScr, vo, so_ + 4 * nsb, st3[t]);  Buf<R>::st(rScr, vo, so_ + 5 * nsb, myD[t * 64]);
         }
-        const int wl = (n - 1) / CH, tl = (n - 1) - wl * CH;
+        // the slab's last cell n-1: piece hl of wave wl, local cell tl
+        const int hl = (n - 1) / (PIPE_NW * PC), rl = (n - 1) - hl * (PIPE_NW * PC), wl = rl / PC, tl = hl * PC + rl % PC;
         if (w == wl && lane_valid) {
             R cv = R(0), d0 = R(0), d1 = R(0), d2 = R(0);
 #pragma unroll
@@ -775,11 +782,13 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
     // ------------------------------------------------------------------ B: backward relay (registers/LDS only)
     // The last wave finishes its last forward pass after every other wave has finished all of theirs (each pass
     // of wave w waits for the same pass of wave w-1), so the relay slots are free for the way back.
-    if (w < PIPE_NW - 1) flag_wait(&bflag[w + 1]);
     STAMP(4);
-    {
+    static_for<NPIECE>([&](auto hr_c) __attribute__((always_inline)) {
+        constexpr int H = NPIECE - 1 - decltype(hr_c)::value;   // pieces from the end of the line to its start
+        // step (H, w) follows (H, w+1), or (H+1, 0) for the last wave
         R x[4] = {R(0), R(0), R(0), R(0)};
-        if (w < PIPE_NW - 1) {
+        if (w < PIPE_NW - 1 || H < NPIECE - 1) {
+            flag_wait(&bflag[(w < PIPE_NW - 1 ? H : H + 1) * PIPE_NW + (w < PIPE_NW - 1 ? w + 1 : 0)]);
             x[0] = relay[0 * 64 + lane]; x[1] = relay[1 * 64 + lane];
             x[2] = relay[2 * 64 + lane]; x[3] = relay[3 * 64 + lane];
         } else if (MODE == 2 && p.xcarry_in && lane_valid) {
@@ -788,7 +797,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
             x[2] = p.xcarry_in[2 * p.plane + cline]; x[3] = p.xcarry_in[3 * p.plane + cline];
         }
 #pragma unroll
-        for (int t = CH - 1; t >= 0; t--) {
+        for (int t = (H + 1) * PC - 1; t >= H * PC; t--) {
             const R c_v = st0[t], c_t = myC[t * 64];
             const R e0 = st1[t], e1 = st2[t], e2 = st3[t], e3 = myD[t * 64];
             // x[num-1] = d[num-1] (Algorithms.h:34): END and SKIP rows carry c' = 0 and so do not look at x[i+1]
@@ -799,12 +808,12 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
         }
         relay[0 * 64 + lane] = x[0]; relay[1 * 64 + lane] = x[1];
         relay[2 * 64 + lane] = x[2]; relay[3 * 64 + lane] = x[3];
-        flag_set(&bflag[w]);
-        if (MODE == 2 && w == 0 && p.xcarry_out && lane_valid) {
+        flag_set(&bflag[H * PIPE_NW + w]);
+        if (MODE == 2 && H == 0 && w == 0 && p.xcarry_out && lane_valid) {
             p.xcarry_out[0 * p.plane + cline] = x[0]; p.xcarry_out[1 * p.plane + cline] = x[1];
             p.xcarry_out[2 * p.plane + cline] = x[2]; p.xcarry_out[3 * p.plane + cline] = x[3];
         }
-    }
+    });
     __builtin_amdgcn_s_setprio(0);
     STAMP(5);
     // no barrier: the transposition tiles of the O phase live in the wave's own c'_T rows (or its own region)
@@ -813,8 +822,9 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
     // ------------------------------------------------------------------ O: scatter + merge, field by field, PC cells per pass
     {
         // does every valid cell of the chunk sit on a segment?  (then whole tiles can be stored)
-        const int len = n - s0 < 0 ? 0 : (n - s0 > CH ? CH : n - s0);
-        const unsigned chunk_mask = len >= 32 ? 0xFFFFFFFFu : ((1u << len) - 1u);
+        unsigned chunk_mask = 0;                                // the wave's cells that lie inside the line
+#pragma unroll
+        for (int t = 0; t < CH; t++) if (ck.cell_ok(t)) chunk_mask |= 1u << t;
         const bool all_seg = __all((!lane_valid) || ((segmask & chunk_mask) == chunk_mask));
         static_for<CK::NPASS>([&](auto pass_c) __attribute__((always_inline)) {
             constexpr int c0 = decltype(pass_c)::value * PC;
@@ -891,7 +901,7 @@ static bool launch_one(fs3d_ctx *c, const SweepParams<R> &p)
     if (DIR == 2 && p.dimz % Chunk<R, DIR, CH>::VW != 0) return false;   // Z moves whole 16-byte row pieces
     const size_t tile = Chunk<R, DIR, CH>::TILE_ELEMS;
     const size_t lds_c = (size_t)PIPE_NW * CH * 64 + (tile <= (size_t)CH * 64 ? 0 : (size_t)PIPE_NW * tile);
-    const size_t lds = ((size_t)PIPE_NW * CH * 64 + lds_c + 8 * 64) * sizeof(R) + 5 * PIPE_NW * sizeof(int);
+    const size_t lds = ((size_t)PIPE_NW * CH * 64 + lds_c + 8 * 64) * sizeof(R) + 5 * Chunk<R, DIR, CH>::NPASS * PIPE_NW * sizeof(int);
     const int grid = n_o * n_tiles;
     constexpr bool HAS_FM = std::is_same<R, float>::value;
     static bool attr_set = false;
@@ -956,7 +966,7 @@ static bool launch_xslab(fs3d_ctx *c, SweepParams<R> p, int half, int b0, int b1
     const int n_o = p.dimy, n_tiles = p.dimz / 64, grid = b1 - b0;
     const size_t tile = Chunk<R, 0, CH>::TILE_ELEMS;
     const size_t lds_c = (size_t)PIPE_NW * CH * 64 + (tile <= (size_t)CH * 64 ? 0 : (size_t)PIPE_NW * tile);
-    const size_t lds = ((size_t)PIPE_NW * CH * 64 + lds_c + 8 * 64) * sizeof(R) + 5 * PIPE_NW * sizeof(int);
+    const size_t lds = ((size_t)PIPE_NW * CH * 64 + lds_c + 8 * 64) * sizeof(R) + 5 * Chunk<R, 0, CH>::NPASS * PIPE_NW * sizeof(int);
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void *)k_sweep_pipe<R, 0, CH, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
