@@ -1,0 +1,123 @@
+// Command-line driver: the reference's FluidSolver3D main (FluidSolver3D/FluidSolver3D.cpp:60-330) on top of
+// libfs3d_hip.so.   fs3d_run <input data> <output prefix> <config> [align] [GPU [n]] [double] [--steps N] [--grid-only FILE]
+//   * reads the config (host/Config.h) and a Shape2D geometry (host/Shape2D.h), prints the grid summary lines
+//     the reference prints ("Grid = X x Y x Z", "NODE_IN points = ..."),
+//   * runs the same loop: dt = cycle length / (frames * time_steps), UpdateBoundaries + TimeStep per step with the
+//     divergence error every 10th step and on the last one, "err = ..." and the progress line per step,
+//   * writes <output prefix>_res.nc through host/NetCDF3.h every out_time_steps steps (GetLayer).
+// `transpose`, `decompose`, `blocking n`, `CSV` of the reference are accepted and ignored (backend tuning switches).
+// There is no CPU backend here: without a GPU the run stops with the library's error.
+// --grid-only FILE: build the grid, dump it (dims, type, bc_vel, bc_temp, vx, vy, vz, T as raw arrays) and exit
+//   without touching the GPU -- used by the CPU tests to compare the C++ loader with its Python twin.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "AdiSolver3D_hip.h"
+#include "Config.h"
+#include "NetCDF3.h"
+#include "Shape2D.h"
+
+template <typename FTYPE>
+static int run(const std::string &data, const std::string &prefix, const fs3d::Config &cfg, bool align, int device, long max_steps, const std::string &grid_only)
+{
+    using namespace fs3d;
+    Grid3D<FTYPE> grid;
+    Grid2D g2;
+    LoadShape2D(grid, g2, data, cfg.dx, cfg.dy, cfg.dz, cfg.depth, cfg.depth_var, cfg.baseT, align);
+    std::printf("Grid = %i x %i x %i\n", grid.dimx, grid.dimy, grid.dimz);                      // FluidSolver3D.cpp:146
+    double inside = 0;
+    for (uint8_t t : grid.type) inside += t == NODE_IN;
+    std::printf("NODE_IN points = %f of total %f, volume = %f\n", inside, (double)grid.dimx * grid.dimy * grid.dimz,
+                inside * grid.dx * grid.dy * grid.dz);                                          // :170
+    if (!grid_only.empty()) {
+        FILE *f = std::fopen(grid_only.c_str(), "wb");
+        if (!f) throw std::runtime_error("cannot create " + grid_only);
+        const int hdr[4] = {grid.dimx, grid.dimy, grid.dimz, (int)sizeof(FTYPE)};
+        std::fwrite(hdr, sizeof hdr, 1, f);
+        std::fwrite(grid.type.data(), 1, grid.type.size(), f); std::fwrite(grid.bc_vel.data(), 1, grid.bc_vel.size(), f);
+        std::fwrite(grid.bc_temp.data(), 1, grid.bc_temp.size(), f);
+        for (const std::vector<FTYPE> *a : {&grid.vx, &grid.vy, &grid.vz, &grid.T}) std::fwrite(a->data(), sizeof(FTYPE), a->size(), f);
+        std::fclose(f);
+        return 0;
+    }
+    FluidParams<FTYPE> params = cfg.useNormalizedParams ? FluidParams<FTYPE>(cfg.Re, cfg.Pr, cfg.lambda)
+                                                        : FluidParams<FTYPE>(cfg.viscosity, cfg.density, cfg.R_specific, cfg.k, cfg.cv);
+    AdiSolver3D<FTYPE> solver;
+    solver.Init(device, grid, params);
+    std::printf("Segments: %i %i %i (x, y, z)\n", solver.numSegs[0], solver.numSegs[1], solver.numSegs[2]);
+
+    const int frames = 1;                                              // single-frame Shape2D inputs
+    const double length = g2.duration;
+    const double dt = length / (frames * cfg.time_steps);              // :196
+    const double finaltime = length * cfg.cycles;
+    const std::string out = prefix + "_res.nc";
+    NetCDF3Writer nc;
+    const float bbox[6] = {g2.bbox[0], g2.bbox[1], 0.0f, g2.bbox[2], g2.bbox[3], (float)cfg.depth};   // BBox3D(bbox2D, depth), :203
+    nc.Create(out, bbox, dt * cfg.out_time_steps, finaltime, cfg.outdimx, cfg.outdimy, cfg.outdimz, cfg.out_vars);
+    std::vector<FTYPE> resVel((size_t)cfg.outdimx * cfg.outdimy * cfg.outdimz * 3);
+    std::vector<double> resT((size_t)cfg.outdimx * cfg.outdimy * cfg.outdimz);
+
+    const auto t0 = std::chrono::steady_clock::now();
+    double t = dt;
+    long steps = 0;
+    for (int i = 0; t < finaltime && (max_steps < 0 || steps < max_steps); t += dt, i++, steps++) {
+        solver.UpdateBoundaries();                                                                       // :244
+        solver.TimeStep((FTYPE)dt, cfg.num_global, cfg.num_local, (i % 10 == 0) || (t + dt >= finaltime)); // :245
+        std::printf("\rerr = %.8f,", solver.diffError);                                                  // AdiSolver3D.cpp:376
+        const float elapsed = std::chrono::duration<float>(std::chrono::steady_clock::now() - t0).count();
+        const float perres = (float)t * 100 / (float)finaltime;                                          // PrintTimeStepInfo, IO.h:455-478
+        if (perres < 2) std::printf(" frame %i\tsubstep %i\t%i%%\t(----- left)", 0, i, (int)perres);
+        else {
+            const float left = elapsed * (100 - perres) / perres;
+            std::printf(" frame %i\tsubstep %i\t%i%%\t(%i h %i m %i s left)", 0, i, (int)perres, ((int)left) / 3600, (((int)left) / 60) % 60, ((int)left) % 60);
+        }
+        std::fflush(stdout);
+        if ((i % cfg.out_time_steps) == 0) {                                                             // :254-264
+            solver.GetLayer(resVel.data(), resT.data(), cfg.outdimx, cfg.outdimy, cfg.outdimz);
+            nc.AppendLayer(resVel.data(), resT.data());
+        }
+    }
+    const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::printf("\n%ld steps in %.3f s: %.1f Mcells/s; %u layers in %s\n", steps, sec,
+                (double)grid.dimx * grid.dimy * grid.dimz * steps / sec / 1e6, nc.NumRecords(), out.c_str());
+    return 0;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 4) {
+        std::printf("Usage: %s <input data> <output prefix> <config file> [align] [GPU [n]] [double] [--steps N] [--grid-only FILE]\n", argv[0]);
+        return 0;
+    }
+    try {
+        fs3d::Config cfg;
+        cfg.Load(argv[3]);
+        if (cfg.problem_dim != "3D") throw std::runtime_error("only `dimension 3D` runs are supported");
+        if (cfg.in_fmt != "Shape2D") throw std::runtime_error("in_fmt " + cfg.in_fmt + ": only Shape2D inputs are supported");
+        if (cfg.solver != "ADI") throw std::runtime_error("solver " + cfg.solver + " is not implemented (the reference implements ADI only)");
+        bool align = false, dbl = false;
+        int device = 0;
+        long max_steps = -1;
+        std::string grid_only;
+        for (int a = 4; a < argc; a++) {
+            const std::string s = argv[a];
+            if (s == "align") align = true;
+            else if (s == "GPU") { if (a + 1 < argc && std::atoi(argv[a + 1]) > 0) a++; }     // the reference's "GPU n": n devices of one process
+            else if (s == "double") dbl = true;
+            else if (s == "--device" && a + 1 < argc) device = std::atoi(argv[++a]);
+            else if (s == "--steps" && a + 1 < argc) max_steps = std::atol(argv[++a]);
+            else if (s == "--grid-only" && a + 1 < argc) grid_only = argv[++a];
+            else if (s == "blocking") { if (a + 1 < argc) a++; }
+            // transpose, decompose, CSV: accepted, no effect
+        }
+        return dbl ? run<double>(argv[1], argv[2], cfg, align, device, max_steps, grid_only)
+                   : run<float>(argv[1], argv[2], cfg, align, device, max_steps, grid_only);
+    } catch (std::exception &e) {
+        std::fprintf(stderr, "\n\nCaught exception:\n%s\n\nTerminating...\n", e.what());     // FluidSolver3D.cpp:313-318
+        return -1;
+    }
+}

@@ -1,0 +1,127 @@
+"""The C++ host side above the C ABI that a user of the reference runs (cmc_fluid_solver_amd/host/):
+Config parser, Shape2D loader, netCDF result writer, command-line driver.  CPU part: the loader against its
+Python twin (itself pinned to the reference's recorded grid dims / NODE_IN counts), the writer read back with
+scipy.  GPU part: the driver end to end against the Python path through the same library."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from cmc_fluid_solver_amd import build as B
+from cmc_fluid_solver_amd import capi, shape2d
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+INPUTS = os.path.join(HERE, "golden", "inputs")
+CASES = {"box_pipe": ("box_pipe_2D_data.txt", "box_pipe_2D_config.txt"),
+         "non_uniform_pipe": ("non_uniform_pipe_2D_data.txt", "non_uniform_pipe_2D_config.txt")}
+
+
+@pytest.fixture(scope="module")
+def driver(built):
+    return B.build_driver()
+
+
+def _grid_dump(path):
+    raw = open(path, "rb").read()
+    nx, ny, nz, esz = np.frombuffer(raw[:16], np.int32)
+    n = nx * ny * nz
+    off = 16
+    out = {}
+    for name in ("type", "bc_vel", "bc_temp"):
+        out[name] = np.frombuffer(raw[off:off + n], np.uint8).reshape(nx, ny, nz); off += n
+    dt = np.float32 if esz == 4 else np.float64
+    for name in ("vx", "vy", "vz", "T"):
+        out[name] = np.frombuffer(raw[off:off + n * esz], dt).reshape(nx, ny, nz); off += n * esz
+    assert off == len(raw)
+    return out
+
+
+@pytest.mark.parametrize("case", list(CASES))
+@pytest.mark.parametrize("prec", ["float", "double"])
+def test_cpp_loader_equals_python_loader(driver, case, prec, tmp_path):
+    data, cfgf = (os.path.join(INPUTS, f) for f in CASES[case])
+    dump = str(tmp_path / "grid.bin")
+    args = [driver, data, str(tmp_path / "out"), cfgf, "align", "--grid-only", dump] + (["double"] if prec == "double" else [])
+    out = subprocess.run(args, check=True, capture_output=True, text=True).stdout
+    nodes, cfg, _ = shape2d.load_case(data, cfgf, align=True)
+    assert "Grid = %d x %d x %d" % nodes.shape in out
+    m = re.search(r"NODE_IN points = ([0-9.]+) of total", out)
+    assert float(m.group(1)) == float((nodes.type == 0).sum())
+    g = _grid_dump(dump)
+    assert np.array_equal(g["type"], nodes.type) and np.array_equal(g["bc_vel"], nodes.bc_vel) and np.array_equal(g["bc_temp"], nodes.bc_temp)
+    dt = np.float32 if prec == "float" else np.float64
+    for name in ("vx", "vy", "vz", "T"):
+        assert np.array_equal(g[name], np.asarray(getattr(nodes, name), dt)), name
+
+
+def test_box_pipe_grid_matches_the_reference_printout(driver, tmp_path):
+    """the reference prints `Grid = 64 x 64 x 64` and 115248 NODE_IN points for the shipped example."""
+    data, cfgf = (os.path.join(INPUTS, f) for f in CASES["box_pipe"])
+    out = subprocess.run([driver, data, str(tmp_path / "o"), cfgf, "align", "--grid-only", str(tmp_path / "g.bin")],
+                         check=True, capture_output=True, text=True).stdout
+    assert "Grid = 64 x 64 x 64" in out and "NODE_IN points = 115248.000000 of total 262144.000000" in out
+
+
+def test_config_errors_are_reported_like_the_reference(driver, tmp_path):
+    bad = tmp_path / "cfg.txt"
+    bad.write_text("dimension 3D\r\nin_fmt Shape2D\r\ngrid_dx 0.02\r\ngrid_dy 0.02\r\ngrid_dz 0.02\r\nout_fmt NetCDF\r\nsolver ADI\r\nout_vars 1 u\r\n")
+    r = subprocess.run([driver, os.path.join(INPUTS, CASES["box_pipe"][0]), str(tmp_path / "o"), str(bad)], capture_output=True, text=True)
+    assert r.returncode != 0 and "cannot find depth!" in r.stderr
+
+
+def test_netcdf_writer_roundtrip(tmp_path):
+    from scipy.io import netcdf_file
+    exe = os.path.join(HERE, "netcdf_writer_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(HERE, "netcdf_writer_test.cpp"), "-o", exe])
+    path = str(tmp_path / "t_res.nc")
+    assert subprocess.run([exe, path], check=True, capture_output=True, text=True).stdout.strip() == "3"
+    f = netcdf_file(path, "r", mmap=False)
+    assert {k: v for k, v in f.dimensions.items()} == {"x": 3, "y": 4, "z": 5, "t": None}
+    assert f.Conventions == b"COARDS" and f.title == b"cmc-fluid-solver results"
+    assert set(f.variables) == {"x", "y", "z", "time", "u", "w", "T"}
+    np.testing.assert_allclose(f.variables["x"][:], np.float32(-0.5) + np.float32(2.0 / 3) * np.arange(3, dtype=np.float32), rtol=1e-6)
+    assert f.variables["x"].units == b"metres" and list(f.variables["z"].actual_range) == [0.0, 1.0]
+    np.testing.assert_array_equal(f.variables["time"][:], [0.0, 0.5, 1.0])
+    assert f.variables["u"].shape == (3, 3, 4, 5) and f.variables["u"].dimensions == ("t", "x", "y", "z")
+    assert f.variables["T"].units == b"tmp" and f.variables["u"].units == b"m/s" and f.variables["w"].var_desc == b"w"
+    assert float(f.variables["T"].missing_value) == 99999.0
+    c = np.arange(60).reshape(3, 4, 5)
+    for layer in range(3):
+        np.testing.assert_array_equal(f.variables["u"][layer], 100.0 * layer + c)
+        np.testing.assert_array_equal(f.variables["w"][layer], 0.5 * c - layer)
+        T = 1.0 + 0.001 * c + layer
+        T.flat[7] = 99999.0
+        np.testing.assert_array_equal(f.variables["T"][layer], T)
+    f.close()
+
+
+@pytest.mark.gpu
+def test_driver_runs_the_shipped_example(driver, tmp_path):
+    """fs3d_run on data/3D box_pipe (the fixture copy): err values and the result layers equal the Python path's."""
+    from scipy.io import netcdf_file
+    data, cfgf = (os.path.join(INPUTS, f) for f in CASES["box_pipe"])
+    prefix = str(tmp_path / "box")
+    nsteps = 21
+    out = subprocess.run([driver, data, prefix, cfgf, "align", "GPU", "--steps", str(nsteps)], check=True, capture_output=True, text=True).stdout
+    errs = [float(x) for x in re.findall(r"err = ([0-9.]+),", out)]
+    assert len(errs) == nsteps
+    nodes, cfg, dt = shape2d.load_case(data, cfgf, align=True)
+    s = capi.Solver(nodes, capi.fluid_params(np.float32, cfg.Re, cfg.Pr, cfg.lam), np.float32)
+    layers, ref_err = [], []
+    for i in range(nsteps):
+        s.UpdateBoundaries()
+        e = s.TimeStep(np.float32(dt), cfg.num_global, cfg.num_local, i % 10 == 0)
+        ref_err.append(e)
+        if i % cfg.out_time_steps == 0:
+            layers.append(s.GetLayer((cfg.outdimx, cfg.outdimy, cfg.outdimz)))
+    np.testing.assert_allclose(errs, [float("%.8f" % e) for e in ref_err], atol=1e-12)
+    f = netcdf_file(prefix + "_res.nc", "r", mmap=False)
+    assert f.variables["u"].shape == (len(layers), cfg.outdimx, cfg.outdimy, cfg.outdimz)
+    for r, (V, T) in enumerate(layers):
+        for c, name in enumerate("uvw"):
+            np.testing.assert_array_equal(f.variables[name][r], V[..., c].astype(np.float64))
+        np.testing.assert_array_equal(f.variables["T"][r], T)
+    np.testing.assert_allclose(f.variables["time"][:], np.arange(len(layers)) * dt * cfg.out_time_steps)
+    f.close()
