@@ -54,6 +54,9 @@ struct SweepParams {
     const R *carry_in; R *carry_out; const R *xcarry_in; R *xcarry_out;
     int ghost_lo, ghost_hi;     // a neighbouring slab's plane stands before / behind the owned planes (X sweep stencils may read it)
     int bundle0;                // first bundle of this launch (line block of the cross-slab pipeline)
+    int seg_index, scr_bundles; // halves: scratch slot = seg_index * scr_bundles + bundle
+    int seg_begin, seg_len;     // halves: segment of the line this launch works on (seg_len 0: the whole line)
+    long long carry_pitch;      // lines per value row of the carry arrays
     int fast_div;               // pipe kernel, fp32: constant divisors are in the range of the division core (kernels_pipe.hip)
     int merge;                  // 0: write next only; 1: also temp_out = merged; 2: merged twice (sweep merge + global merge)
 };
@@ -74,7 +77,8 @@ struct fs3d_ctx {
     int spare = 4;
     uint16_t *code = nullptr;
     void *node = nullptr;       // 4 x ncell
-    void *scr = nullptr;        // 6 x ncell (LINE kernel only, allocated on demand)
+    void *scr = nullptr;        // >= 6 x ncell: rows of the thread-per-line kernel / of the pipe kernel's halves (allocated on demand)
+    size_t scr_bytes = 0;
     // compact list of NODE_BOUND / NODE_VALVE cells (AdiSolver3D.cpp:286-311)
     int *bnd_idx = nullptr;
     void *bnd_val[4] = {};
@@ -103,6 +107,8 @@ struct fs3d_ctx {
     void *local = nullptr;         // fs3d_local_group* (in-process transport)
     void *carry[4] = {};           // cross-slab X sweep: fwd in/out (6 x plane), bwd in/out (4 x plane)
     int opt_div_core = 1;          // FS3D_OPT_DIV_CORE
+    void *seg_carry[2] = {};       // segmented long-line sweeps: forward (6 x lines) and backward (4 x lines) carries
+    long long seg_carry_lines = 0;
     int *redo = nullptr;           // pipe kernel, fp32: per-bundle "compute again with full divisions" flags (all zero between sweeps)
     int redo_cap = 0;
     int rank = 0, nranks = 1;
@@ -116,5 +122,7 @@ template <typename R> bool launch_sweep_pipe(fs3d_ctx *c, int dir, const SweepPa
 // X sweep halves of an x-slab for the bundles [b0, b1) (64 lines each, line = j*dimz + k); false: dims unsupported
 template <typename R> bool xslab_pipe_supported(const SweepParams<R> &p);
 template <typename R> bool launch_xslab_pipe(fs3d_ctx *c, SweepParams<R> p, int half, int b0, int b1);
+// lines longer than the pipe kernel holds: the sweep as a sequence of segment halves on one GPU; false: unsupported
+template <typename R> bool launch_sweep_pipe_segmented(fs3d_ctx *c, int dir, SweepParams<R> p);
 template <typename R> void launch_xsweep_fwd(fs3d_ctx *c, const SweepParams<R> &p, const void *carry_in, void *carry_out, long long l0, long long l1);
 template <typename R> void launch_xsweep_bwd(fs3d_ctx *c, const SweepParams<R> &p, const void *xcarry_in, void *xcarry_out, long long l0, long long l1);

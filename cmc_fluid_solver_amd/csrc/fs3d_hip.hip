@@ -235,6 +235,7 @@ extern "C" void fs3d_destroy(fs3d_ctx *c)
     fs3d_comm_destroy(c);
     for (int l = 0; l < 5; l++) if (c->lay[l]) hipFree(c->lay[l]);
     if (c->redo) hipFree(c->redo);
+    for (int i = 0; i < 2; i++) if (c->seg_carry[i]) hipFree(c->seg_carry[i]);
     if (c->code) hipFree(c->code);
     if (c->node) hipFree(c->node);
     if (c->scr) hipFree(c->scr);
@@ -494,6 +495,7 @@ static void fill_params(fs3d_ctx *c, SweepParams<R> &p, int dir, double dt_, int
     p.merge = merge;
     p.stamps = nullptr;
     p.carry_in = nullptr; p.carry_out = nullptr; p.xcarry_in = nullptr; p.xcarry_out = nullptr; p.bundle0 = 0;
+    p.seg_begin = 0; p.seg_len = 0; p.carry_pitch = c->plane; p.seg_index = 0; p.scr_bundles = 0;
     p.ghost_lo = c->x_offset > 0; p.ghost_hi = c->x_offset + c->dimx < c->dimx_global;
     // division core (fp32 pipe kernel): the constant divisors must be plain numbers in [2^-30, 2^60)
     auto plain = [](double v) { v = v < 0 ? -v : v; return v >= 9.313225746154785e-10 && v < 1.152921504606847e18; };
@@ -504,6 +506,7 @@ static fs3d_status ensure_scratch(fs3d_ctx *c)
 {
     if (c->scr) return FS3D_OK;
     HIPCHK(c, hipMalloc(&c->scr, (size_t)6 * c->ncell * c->esize));
+    c->scr_bytes = (size_t)6 * c->ncell * c->esize;
     return FS3D_OK;
 }
 
@@ -568,8 +571,15 @@ static fs3d_status sweep_buffers(fs3d_ctx *c, int dir, double dt, int b_cur, int
     }
     bool done = false;
     if (c->opt_kernel != FS3D_SWEEP_LINE) done = launch_sweep_pipe<R>(c, dir, p);
+    if (!done && c->opt_kernel != FS3D_SWEEP_LINE) {
+        // lines longer than one launch holds on chip: segment by segment, rows through the HBM scratch
+        fs3d_status st = ensure_scratch(c);
+        if (st) return st;
+        p.scr_ = (R *)c->scr;
+        done = launch_sweep_pipe_segmented<R>(c, dir, p);
+    }
     if (!done) {
-        if (c->opt_kernel == FS3D_SWEEP_PIPE) { rec_end(c); return fail(c, FS3D_ERR_UNSUPPORTED, "pipelined sweep kernel does not support these dims"); }
+        if (c->opt_kernel == FS3D_SWEEP_PIPE) { rec_end(c); return fail(c, FS3D_ERR_UNSUPPORTED, "pipelined sweep kernel does not support these dims (" + c->err + ")"); }
         fs3d_status st = ensure_scratch(c);
         if (st) return st;
         fill_params<R>(c, p, dir, dt, b_cur, b_temp, b_next, b_tout, merge);

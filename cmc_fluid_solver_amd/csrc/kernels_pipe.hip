@@ -357,7 +357,9 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
     if (MODE != 0) lb += p.bundle0;
     const int tile_id = MODE != 0 ? lb % n_tiles : lb / n_o, o = MODE != 0 ? lb / n_tiles : lb - tile_id * n_o;
 
-    const int n = DIR == 0 ? p.dimx : (DIR == 1 ? p.dimy : p.dimz);
+    const int n_full = DIR == 0 ? p.dimx : (DIR == 1 ? p.dimy : p.dimz);
+    // slab halves may work on a segment [seg_begin, seg_begin + seg_len) of the line (lines longer than the kernel holds)
+    const int n = (MODE != 0 && p.seg_len) ? p.seg_len : n_full;
     const int la_len = DIR == 2 ? p.dimy : p.dimz;          // length of the lane axis
     const int l = tile_id * 64 + lane;
     const long long so = DIR == 0 ? (long long)p.dimz : p.plane;
@@ -392,13 +394,16 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
 
     Chunk<R, DIR, CH> ck;
     ck.n = n; ck.wpc = w * Chunk<R, DIR, CH>::PC; ck.lane = lane; ck.lane_valid = l < la_len;
-    ck.slo = (DIR == 0 && p.ghost_lo) ? -1 : 0; ck.shi = (DIR == 0 && p.ghost_hi) ? n : n - 1;
+    // one cell beyond the owned range is readable where the line goes on: a neighbouring slab's ghost plane (X) or the
+    // neighbouring segment of the same line
+    ck.slo = ((DIR == 0 && p.ghost_lo) || (MODE != 0 && p.seg_begin > 0)) ? -1 : 0;
+    ck.shi = ((DIR == 0 && p.ghost_hi) || (MODE != 0 && p.seg_len && p.seg_begin + p.seg_len < n_full)) ? n : n - 1;
     {
         // wave-uniform element offset of (lane 0, cell 0) from the first owned cell, then + the halo plane
         const long long ub = DIR == 0 ? (long long)o * p.dimz + tile_id * 64
                            : (DIR == 1 ? (long long)o * p.plane + tile_id * 64 : (long long)o * p.plane + (long long)tile_id * 64 * p.dimz);
-        ck.row0 = (unsigned)((ub + p.plane) * (long long)sizeof(R));
         const long long ss = DIR == 0 ? p.plane : (DIR == 1 ? (long long)p.dimz : 1LL);
+        ck.row0 = (unsigned)((ub + p.plane + (MODE != 0 ? (long long)p.seg_begin * ss : 0LL)) * (long long)sizeof(R));
         ck.ssb = (unsigned)(ss * (long long)sizeof(R));
         const int lc = l < la_len ? lane : la_len - 1 - tile_id * 64;   // clamp lanes past the lane axis
         ck.vob = (unsigned)(DIR == 2 ? lc * p.dimz : lc) * (unsigned)sizeof(R);
@@ -644,9 +649,12 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
             });
         }
     }
-    // slab halves: the eliminated rows travel through the HBM scratch (6 arrays without halo planes, like the node values)
-    const rsrc_t rScr = __builtin_amdgcn_make_buffer_rsrc((void *)(p.scr_ - p.plane), 0, (int)(5u * nsb + ck.fbytes), 0x00020000);
-    const long long cline = (long long)o * p.dimz + l;      // this lane's line in the carry arrays [value][line] (X sweep)
+    // halves: the eliminated rows travel through the HBM scratch in the bundle's own layout -- [segment][bundle][array][row of
+    // this workgroup's LDS order][64 lanes] -- so that every access is a whole 64-lane row whatever the sweep direction
+    constexpr long long SCR_ARR = (long long)PIPE_NW * CH * 64;
+    R *const scr = p.scr_ + (((long long)p.seg_index * p.scr_bundles + lb) * 6) * SCR_ARR + (long long)s0 * 64 + lane;
+    const long long cline = (long long)o * la_len + l;      // this lane's line in the carry arrays [value][line]
+    const long long cpitch = p.carry_pitch;                 // lines per value row
 
     // ------------------------------------------------------------------ F: forward relays, staggered
     // The four right-hand sides (T, U, V, W) are four independent first-order recurrences once each pass
@@ -698,8 +706,8 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
             cp = relay[(2 * VAR) * 64 + lane]; dp = relay[(2 * VAR + 1) * 64 + lane];                     \
         } else if (MODE == 1 && p.carry_in && lane_valid) {                                               \
             /* the recurrence continues the slab below (k_xsweep_fwd's carry layout) */                  \
-            cp = p.carry_in[(VAR == 3 ? 1 : 0) * p.plane + cline];                                        \
-            dp = p.carry_in[(2 + VAR) * p.plane + cline];                                                 \
+            cp = p.carry_in[(VAR == 3 ? 1 : 0) * cpitch + cline];                                        \
+            dp = p.carry_in[(2 + VAR) * cpitch + cline];                                                 \
         }                                                                                                 \
         R vis = VAR == 3 ? p.vis_t : p.vis_v, bb = VAR == 3 ? p.b_t : p.b_v;                              \
         /* opaque per pass: otherwise U computes every a, c once and parks them in scratch for V and W */ \
@@ -746,11 +754,9 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
         // forward half of a slab: rows to the scratch, the carries of the slab's last cell to the next rank
 #pragma unroll
         for (int t = 0; t < CH; t++) {
-            const unsigned vo = ck.cell_ok(t) ? ck.vob_st : BUF_OOB;
-            const unsigned so_ = ck.soff(t);
-            Buf<R>::st(rScr, vo, so_, st0[t]);            Buf<R>::st(rScr, vo, so_ + nsb, myC[t * 64]);
-            Buf<R>::st(rScr, vo, so_ + 2 * nsb, st1[t]);  Buf<R>::st(rScr, vo, so_ + 3 * nsb, st2[t]);
-            Buf<R>::st(rScr, vo, so_ + 4 * nsb, st3[t]);  Buf<R>::st(rScr, vo, so_ + 5 * nsb, myD[t * 64]);
+            scr[0 * SCR_ARR + t * 64] = st0[t]; scr[1 * SCR_ARR + t * 64] = myC[t * 64];
+            scr[2 * SCR_ARR + t * 64] = st1[t]; scr[3 * SCR_ARR + t * 64] = st2[t];
+            scr[4 * SCR_ARR + t * 64] = st3[t]; scr[5 * SCR_ARR + t * 64] = myD[t * 64];
         }
         // the slab's last cell n-1: piece hl of wave wl, local cell tl
         const int hl = (n - 1) / (PIPE_NW * PC), rl = (n - 1) - hl * (PIPE_NW * PC), wl = rl / PC, tl = hl * PC + rl % PC;
@@ -758,9 +764,9 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
             R cv = R(0), d0 = R(0), d1 = R(0), d2 = R(0);
 #pragma unroll
             for (int t = 0; t < CH; t++) if (t == tl) { cv = st0[t]; d0 = st1[t]; d1 = st2[t]; d2 = st3[t]; }
-            p.carry_out[0 * p.plane + cline] = cv;  p.carry_out[1 * p.plane + cline] = myC[tl * 64];
-            p.carry_out[2 * p.plane + cline] = d0;  p.carry_out[3 * p.plane + cline] = d1;
-            p.carry_out[4 * p.plane + cline] = d2;  p.carry_out[5 * p.plane + cline] = myD[tl * 64];
+            p.carry_out[0 * cpitch + cline] = cv;  p.carry_out[1 * cpitch + cline] = myC[tl * 64];
+            p.carry_out[2 * cpitch + cline] = d0;  p.carry_out[3 * cpitch + cline] = d1;
+            p.carry_out[4 * cpitch + cline] = d2;  p.carry_out[5 * cpitch + cline] = myD[tl * 64];
         }
         return;
     }
@@ -768,11 +774,9 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
         // backward half: rows back from the scratch.  Cells past the slab get c' = -1, d' = 0: x passes through them.
 #pragma unroll
         for (int t = 0; t < CH; t++) {
-            const unsigned so_ = ck.soff(t);
             const bool in = ck.cell_ok(t);
-            const R a0 = Buf<R>::ld(rScr, ck.vob, so_), a1 = Buf<R>::ld(rScr, ck.vob, so_ + nsb);
-            const R a2 = Buf<R>::ld(rScr, ck.vob, so_ + 2 * nsb), a3 = Buf<R>::ld(rScr, ck.vob, so_ + 3 * nsb);
-            const R a4 = Buf<R>::ld(rScr, ck.vob, so_ + 4 * nsb), a5 = Buf<R>::ld(rScr, ck.vob, so_ + 5 * nsb);
+            const R a0 = scr[0 * SCR_ARR + t * 64], a1 = scr[1 * SCR_ARR + t * 64], a2 = scr[2 * SCR_ARR + t * 64];
+            const R a3 = scr[3 * SCR_ARR + t * 64], a4 = scr[4 * SCR_ARR + t * 64], a5 = scr[5 * SCR_ARR + t * 64];
             st0[t] = in ? a0 : R(-1); myC[t * 64] = in ? a1 : R(-1);
             st1[t] = in ? a2 : R(0); st2[t] = in ? a3 : R(0); st3[t] = in ? a4 : R(0); myD[t * 64] = in ? a5 : R(0);
             if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
@@ -793,8 +797,8 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
             x[2] = relay[2 * 64 + lane]; x[3] = relay[3 * 64 + lane];
         } else if (MODE == 2 && p.xcarry_in && lane_valid) {
             // x of the first cell of the slab above (k_xsweep_bwd's carry layout)
-            x[0] = p.xcarry_in[0 * p.plane + cline]; x[1] = p.xcarry_in[1 * p.plane + cline];
-            x[2] = p.xcarry_in[2 * p.plane + cline]; x[3] = p.xcarry_in[3 * p.plane + cline];
+            x[0] = p.xcarry_in[0 * cpitch + cline]; x[1] = p.xcarry_in[1 * cpitch + cline];
+            x[2] = p.xcarry_in[2 * cpitch + cline]; x[3] = p.xcarry_in[3 * cpitch + cline];
         }
 #pragma unroll
         for (int t = (H + 1) * PC - 1; t >= H * PC; t--) {
@@ -810,8 +814,8 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
         relay[2 * 64 + lane] = x[2]; relay[3 * 64 + lane] = x[3];
         flag_set(&bflag[H * PIPE_NW + w]);
         if (MODE == 2 && H == 0 && w == 0 && p.xcarry_out && lane_valid) {
-            p.xcarry_out[0 * p.plane + cline] = x[0]; p.xcarry_out[1 * p.plane + cline] = x[1];
-            p.xcarry_out[2 * p.plane + cline] = x[2]; p.xcarry_out[3 * p.plane + cline] = x[3];
+            p.xcarry_out[0 * cpitch + cline] = x[0]; p.xcarry_out[1 * cpitch + cline] = x[1];
+            p.xcarry_out[2 * cpitch + cline] = x[2]; p.xcarry_out[3 * cpitch + cline] = x[3];
         }
     });
     __builtin_amdgcn_s_setprio(0);
@@ -958,24 +962,40 @@ bool launch_sweep_pipe<double>(fs3d_ctx *c, int dir, const SweepParams<double> &
     return false;
 }
 
-// ---- X sweep halves of an x-slab (cross-slab pipeline, fs3d_hip.hip: xsweep_multi) -------------------------
-template <typename R, int CH>
-static bool launch_xslab(fs3d_ctx *c, SweepParams<R> p, int half, int b0, int b1)
+// ---- sweep halves: X sweep of an x-slab (cross-slab pipeline, fs3d_hip.hip: xsweep_multi) and the segments of
+// ---- lines longer than one launch holds on chip (launch_sweep_pipe_segmented) ------------------------------
+// the context's scratch, at least `elems` elements of R (shared with the thread-per-line kernel, which needs 6 per cell)
+template <typename R>
+static bool pipe_scratch(fs3d_ctx *c, size_t elems)
+{
+    const size_t bytes = std::max(elems, (size_t)6 * (size_t)c->ncell) * sizeof(R);
+    if (c->scr && c->scr_bytes >= bytes) return true;
+    if (c->scr) { hipStreamSynchronize(c->stream); hipFree(c->scr); c->scr = nullptr; c->scr_bytes = 0; }
+    if (hipMalloc(&c->scr, bytes) != hipSuccess) return false;
+    c->scr_bytes = bytes;
+    return true;
+}
+
+template <typename R, int DIR, int CH>
+static bool launch_half(fs3d_ctx *c, SweepParams<R> p, int half, int b0, int b1)
 {
     constexpr bool HAS_FM = std::is_same<R, float>::value;
-    const int n_o = p.dimy, n_tiles = p.dimz / 64, grid = b1 - b0;
-    const size_t tile = Chunk<R, 0, CH>::TILE_ELEMS;
+    const int la_len = DIR == 2 ? p.dimy : p.dimz;
+    const int n_o = DIR == 0 ? p.dimy : p.dimx, n_tiles = (la_len + 63) / 64, grid = b1 - b0;
+    if (DIR == 2 && p.dimz % Chunk<R, DIR, CH>::VW != 0) { c->err = "pipe halves: dimz is not a multiple of the 16-byte vector"; return false; }
+    const size_t tile = Chunk<R, DIR, CH>::TILE_ELEMS;
     const size_t lds_c = (size_t)PIPE_NW * CH * 64 + (tile <= (size_t)CH * 64 ? 0 : (size_t)PIPE_NW * tile);
-    const size_t lds = ((size_t)PIPE_NW * CH * 64 + lds_c + 8 * 64) * sizeof(R) + 5 * Chunk<R, 0, CH>::NPASS * PIPE_NW * sizeof(int);
+    const size_t lds = ((size_t)PIPE_NW * CH * 64 + lds_c + 8 * 64) * sizeof(R) + 5 * Chunk<R, DIR, CH>::NPASS * PIPE_NW * sizeof(int);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)k_sweep_pipe<R, 0, CH, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
-        if (hipFuncSetAttribute((const void *)k_sweep_pipe<R, 0, CH, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
-        if (HAS_FM && hipFuncSetAttribute((const void *)k_sweep_pipe<R, 0, CH, HAS_FM, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+        if (hipFuncSetAttribute((const void *)k_sweep_pipe<R, DIR, CH, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { c->err = std::string("pipe halves: hipFuncSetAttribute: ") + hipGetErrorString(hipGetLastError()); return false; }
+        if (hipFuncSetAttribute((const void *)k_sweep_pipe<R, DIR, CH, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+        if (HAS_FM && hipFuncSetAttribute((const void *)k_sweep_pipe<R, DIR, CH, HAS_FM, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
         attr_set = true;
     }
     if (grid <= 0) return true;
     p.bundle0 = b0;
+    if (!p.scr_ || p.scr_bundles < b1) { c->err = "pipe halves: scratch not prepared"; return false; }
     if (half == 1) {
         if (HAS_FM && p.fast_div) {
             if (c->redo_cap < grid) {
@@ -985,13 +1005,13 @@ static bool launch_xslab(fs3d_ctx *c, SweepParams<R> p, int half, int b0, int b1
                 if (hipMemsetAsync(c->redo, 0, (size_t)cap * sizeof(int), c->stream) != hipSuccess) return false;
                 c->redo_cap = cap;
             }
-            hipLaunchKernelGGL((k_sweep_pipe<R, 0, CH, HAS_FM, 1>), dim3((unsigned)grid), dim3(PIPE_NW * 64), lds, c->stream, p, n_o, n_tiles, c->redo);
-            hipLaunchKernelGGL((k_sweep_pipe<R, 0, CH, false, 1>), dim3((unsigned)grid), dim3(PIPE_NW * 64), lds, c->stream, p, n_o, n_tiles, c->redo);
+            hipLaunchKernelGGL((k_sweep_pipe<R, DIR, CH, HAS_FM, 1>), dim3((unsigned)grid), dim3(PIPE_NW * 64), lds, c->stream, p, n_o, n_tiles, c->redo);
+            hipLaunchKernelGGL((k_sweep_pipe<R, DIR, CH, false, 1>), dim3((unsigned)grid), dim3(PIPE_NW * 64), lds, c->stream, p, n_o, n_tiles, c->redo);
         } else {
-            hipLaunchKernelGGL((k_sweep_pipe<R, 0, CH, false, 1>), dim3((unsigned)grid), dim3(PIPE_NW * 64), lds, c->stream, p, n_o, n_tiles, (int *)nullptr);
+            hipLaunchKernelGGL((k_sweep_pipe<R, DIR, CH, false, 1>), dim3((unsigned)grid), dim3(PIPE_NW * 64), lds, c->stream, p, n_o, n_tiles, (int *)nullptr);
         }
     } else {
-        hipLaunchKernelGGL((k_sweep_pipe<R, 0, CH, false, 2>), dim3((unsigned)grid), dim3(PIPE_NW * 64), lds, c->stream, p, n_o, n_tiles, (int *)nullptr);
+        hipLaunchKernelGGL((k_sweep_pipe<R, DIR, CH, false, 2>), dim3((unsigned)grid), dim3(PIPE_NW * 64), lds, c->stream, p, n_o, n_tiles, (int *)nullptr);
     }
     return true;
 }
@@ -1006,9 +1026,62 @@ template <> bool xslab_pipe_supported<double>(const SweepParams<double> &p)
 }
 template <> bool launch_xslab_pipe<float>(fs3d_ctx *c, SweepParams<float> p, int half, int b0, int b1)
 {
-    return p.dimx <= PIPE_NW * 16 ? launch_xslab<float, 16>(c, p, half, b0, b1) : launch_xslab<float, 32>(c, p, half, b0, b1);
+    const int nbt = p.dimy * (p.dimz / 64);
+    if (!pipe_scratch<float>(c, (size_t)nbt * 6 * PIPE_NW * (p.dimx <= PIPE_NW * 16 ? 16 : 32) * 64)) return false;
+    p.scr_ = (float *)c->scr; p.scr_bundles = nbt; p.seg_index = 0;
+    return p.dimx <= PIPE_NW * 16 ? launch_half<float, 0, 16>(c, p, half, b0, b1) : launch_half<float, 0, 32>(c, p, half, b0, b1);
 }
 template <> bool launch_xslab_pipe<double>(fs3d_ctx *c, SweepParams<double> p, int half, int b0, int b1)
 {
-    return launch_xslab<double, 16>(c, p, half, b0, b1);
+    const int nbt = p.dimy * (p.dimz / 64);
+    if (!pipe_scratch<double>(c, (size_t)nbt * 6 * PIPE_NW * 16 * 64)) return false;
+    p.scr_ = (double *)c->scr; p.scr_bundles = nbt; p.seg_index = 0;
+    return launch_half<double, 0, 16>(c, p, half, b0, b1);
+}
+
+// A line of n cells, n above what one launch holds on chip (8 waves x CH cells): forward halves of the segments in
+// line order, backward halves in reverse, the carries of a segment's last / first cell in two per-line arrays that
+// each bundle reads before it overwrites them.  Cell for cell the arithmetic of the unsegmented sweep.
+template <typename R, int DIR, int CH>
+static bool run_segments(fs3d_ctx *c, SweepParams<R> p)
+{
+    const int n = DIR == 0 ? p.dimx : (DIR == 1 ? p.dimy : p.dimz);
+    const int la_len = DIR == 2 ? p.dimy : p.dimz, n_o = DIR == 0 ? p.dimy : p.dimx;
+    const int seg = PIPE_NW * CH, nseg = (n + seg - 1) / seg, nb = n_o * ((la_len + 63) / 64);
+    const long long lines = (long long)n_o * la_len;
+    if (c->seg_carry_lines < lines) {
+        for (int i = 0; i < 2; i++) if (c->seg_carry[i]) { hipStreamSynchronize(c->stream); hipFree(c->seg_carry[i]); c->seg_carry[i] = nullptr; }
+        if (hipMalloc(&c->seg_carry[0], 6 * (size_t)lines * sizeof(R)) != hipSuccess) { c->err = "pipe segments: hipMalloc of the carries failed"; return false; }
+        if (hipMalloc(&c->seg_carry[1], 4 * (size_t)lines * sizeof(R)) != hipSuccess) return false;
+        c->seg_carry_lines = lines;
+    }
+    p.carry_pitch = lines;
+    if (!pipe_scratch<R>(c, (size_t)nseg * nb * 6 * PIPE_NW * CH * 64)) { c->err = "pipe segments: hipMalloc of the scratch failed"; return false; }
+    p.scr_ = (R *)c->scr; p.scr_bundles = nb;
+    for (int s = 0; s < nseg; s++) {
+        p.seg_index = s;
+        p.seg_begin = s * seg; p.seg_len = std::min(seg, n - s * seg);
+        p.carry_in = s > 0 ? (const R *)c->seg_carry[0] : nullptr; p.carry_out = (R *)c->seg_carry[0];
+        if (!launch_half<R, DIR, CH>(c, p, 1, 0, nb)) return false;
+    }
+    for (int s = nseg - 1; s >= 0; s--) {
+        p.seg_index = s;
+        p.seg_begin = s * seg; p.seg_len = std::min(seg, n - s * seg);
+        p.xcarry_in = s < nseg - 1 ? (const R *)c->seg_carry[1] : nullptr; p.xcarry_out = (R *)c->seg_carry[1];
+        if (!launch_half<R, DIR, CH>(c, p, 2, 0, nb)) return false;
+    }
+    return true;
+}
+
+template <> bool launch_sweep_pipe_segmented<float>(fs3d_ctx *c, int dir, SweepParams<float> p)
+{
+    if ((unsigned long long)p.fstride * 4ull * sizeof(float) >= (1ull << 32)) return false;
+    if (dir == 0 && (p.ghost_lo || p.ghost_hi)) return false;          // a slab's X sweep has its own path
+    return dir == 0 ? run_segments<float, 0, 32>(c, p) : (dir == 1 ? run_segments<float, 1, 32>(c, p) : run_segments<float, 2, 32>(c, p));
+}
+template <> bool launch_sweep_pipe_segmented<double>(fs3d_ctx *c, int dir, SweepParams<double> p)
+{
+    if ((unsigned long long)p.fstride * 4ull * sizeof(double) >= (1ull << 32)) return false;
+    if (dir == 0 && (p.ghost_lo || p.ghost_hi)) return false;
+    return dir == 0 ? run_segments<double, 0, 16>(c, p) : (dir == 1 ? run_segments<double, 1, 16>(c, p) : run_segments<double, 2, 16>(c, p));
 }

@@ -227,9 +227,9 @@ def test_long_lines_pipe_kernel(built, dims):
 
 def test_pipe_kernel_is_really_used(built):
     """FS3D_SWEEP_PIPE must not silently fall back: it errors on dims it cannot take."""
-    g = grids.box(12, 12, 300, h=0.02)      # 300-cell Z lines: longer than 8 waves x 32 cells
+    g = grids.box(12, 12, 70, h=0.02)       # 70-cell Z lines: not a whole number of 16-byte row pieces
     s, o = make_pair(g, np.float32, capi.SWEEP_PIPE)
-    s.sweep(0, DT, capi.LAYER_CUR, capi.LAYER_TEMP, capi.LAYER_NEXT)      # X lines (12) are fine
+    s.sweep(0, DT, capi.LAYER_CUR, capi.LAYER_TEMP, capi.LAYER_NEXT)      # X lines are fine
     with pytest.raises(capi.Fs3dError) as ei:
         s.sweep(2, DT, capi.LAYER_CUR, capi.LAYER_TEMP, capi.LAYER_NEXT)
     assert ei.value.status == capi.ERR_UNSUPPORTED
@@ -457,3 +457,27 @@ def test_masked_geometry_at_256_kernels_agree_and_time(built):
     for v in range(4):
         assert np.array_equal(res[0][0][v], res[1][0][v]), "field %d: pipelined != thread-per-line" % v
     assert res[0][1] == res[1][1]
+
+
+@pytest.mark.parametrize("dims,dtype", [((300, 12, 72), np.float32), ((12, 520, 72), np.float32), ((10, 70, 516), np.float32),
+                                        ((264, 260, 12), np.float32), ((200, 12, 68), np.float64), ((10, 66, 260), np.float64)])
+def test_lines_longer_than_one_launch_holds(built, dims, dtype):
+    """Lines above 256 cells (fp32) / 128 cells (fp64): the pipelined kernel runs them as segments -- forward halves
+    in line order, backward halves in reverse, carries per line, rows through the HBM scratch.  Forced with
+    FS3D_SWEEP_PIPE (a silent fall-back to the thread-per-line kernel would pass for the wrong reason); obstacle
+    inside (segment ends anywhere relative to the cuts), partly empty lane tiles; sweeps and 2 steps against the oracle.
+    (dimz a multiple of 4: the Z sweep of the pipelined kernel moves 16-byte row pieces.)"""
+    O = _oracle()
+    g = grids.box_with_obstacle(*dims, h=0.02)
+    s, o = make_pair(g, dtype, capi.SWEEP_PIPE)
+    seed_state(s, o, g, dtype)
+    for d in range(3):
+        s.sweep(d, DT, capi.LAYER_CUR, capi.LAYER_TEMP, capi.LAYER_NEXT, merge=True)
+        o.sweep(d, DT, O.L_CUR, O.L_TEMP, O.L_NEXT); o.merge(O.L_NEXT, O.L_TEMP)
+        assert_layers_equal(s, o, capi.LAYER_NEXT, O.L_NEXT, "next, dir %d" % d)
+        assert_layers_equal(s, o, capi.LAYER_TEMP, O.L_TEMP, "temp, dir %d" % d)
+    for step in range(2):
+        s.UpdateBoundaries(); o.update_boundaries()
+        e = s.TimeStep(DT, 4, 2, True); rc, eo = o.time_step(DT, 4, 2, True)
+        assert e == pytest.approx(eo, rel=1e-12)
+    assert_layers_equal(s, o, capi.LAYER_CUR, O.L_CUR, "cur")
