@@ -1,27 +1,29 @@
 // Wave-pipelined exact Thomas sweep (FS3D_SWEEP_PIPE) for CDNA4.
 //
 // Work decomposition
-//   bundle    = 64 neighbouring grid lines of the sweep direction (lanes of a wave),
-//               whole length n = dim along the sweep axis.  One workgroup per bundle.
-//   workgroup = NW = 8 waves; wave w owns cells [w*CH, (w+1)*CH) of every line of the bundle.
+//   bundle    = 64 neighbouring grid lines of the sweep direction (the lanes of a wave), whole length n = dim along
+//               the sweep axis (or a segment / slab piece of it, MODE 1/2).  One workgroup per bundle.
+//   workgroup = NW = 8 waves; wave w owns CH cells of every line of the bundle as CH/PC pieces of PC = 16 cells:
+//               piece h of wave w = cells [h*NW*PC + w*PC, +PC).  Consecutive pieces belong to consecutive waves.
 //   X, Y sweeps: lanes run along k (unit stride)  -> every global access is a coalesced row.
-//   Z sweep    : lanes run along j, a thread's CH cells are contiguous in memory.
+//   Z sweep    : lanes run along j, a piece is 64 contiguous bytes of a row: [64 lines][16 cells] tiles move in
+//                16-byte lane accesses and are transposed through a padded per-wave LDS tile.
 //
-// Phases (bit-exact w.r.t. the sequential reference, Algorithms.h:21-38)
-//   P  all waves in parallel, FIELD-MAJOR: one field of the chunk at a time is pulled into a
-//      register array (CH+2 loads in flight per lane), consumed, and its registers recycled.
-//      Z sweep: the chunk is moved as a [64 lines][CH cells] tile in whole 128-byte rows
-//      (16 bytes per lane) and transposed through a padded LDS tile, so HBM sees cache lines.
-//      Result per cell: q, dU, dV, dW in registers, dT in LDS (rows of fs3d_rows.h).
-//   F  forward elimination as a relay: wave 0 eliminates its chunk, hands (c',d') of its
-//      last cell to wave 1 through LDS, ... The recurrence is the reference's, cell by cell;
-//      c'_uvw,d'_U,d'_V,d'_W overwrite the row data in registers, c'_T,d'_T live in LDS.
-//   B  back-substitution as the reverse relay, registers/LDS only: x overwrites c',d'.
-//   O  all waves in parallel, field-major: scatter x to `next` (UpdateSegment,
-//      AdiSolver3D.cpp:707-730) and apply the merge into temp (TimeLayer3D.h:415-436).
-// Nothing but the 8 input and 8 output words per cell (+2-byte cell code) moves to/from HBM:
-// the 6 words/cell of c',d' that a thread-per-line kernel spills stay on chip (128 VGPRs
-// per lane + 128 KiB LDS per workgroup for a 256-cell fp32 line).
+// Phases (every floating-point operation on a cell is the sequential reference's, Algorithms.h:21-38)
+//   P  all waves in parallel, one sub-pass per piece, software pipeline over nine field groups (group k+1 issued
+//      before group k is consumed): the INTERIOR row of every cell -> q, dU, dV, dW in registers, dT in LDS;
+//      a wave-uniform, rare fix-up pass for the other row kinds (segment ends, cells off every segment).
+//   F  forward elimination: four staggered passes (T, U, V, W) over the pieces in line order; a pass of a piece
+//      starts when the same pass of the piece before it has finished (LDS flag, no workgroup barrier).
+//      c'_uvw, d'_U, d'_V, d'_W overwrite the row data in registers, c'_T, d'_T live in LDS.
+//      fp32: divisions by the scaling-free core of the IEEE expansion, per-bundle redo flag (FM).
+//   B  back-substitution over the pieces in reverse order, registers/LDS only: x overwrites c', d'.
+//   O  all waves in parallel: scatter x to `next` (UpdateSegment, AdiSolver3D.cpp:707-730) and apply the merge
+//      into temp (TimeLayer3D.h:415-436).
+// A whole sweep moves nothing but the 8 input and 8 output words per cell (+2-byte cell code) to/from HBM: the
+// 6 words/cell of c', d' that a thread-per-line kernel spills stay on chip (128 VGPRs per lane + 128 KiB LDS per
+// workgroup for 256 fp32 cells).  The halves (MODE 1/2) pass them through an HBM scratch instead: lines of any
+// length, x-slabs of a multi-GPU run.
 #include <algorithm>
 #include <type_traits>
 #include <utility>
@@ -271,12 +273,10 @@ struct Chunk {
     // one cell of this lane (any field-relative uniform byte offset)
     __device__ __forceinline__ R at(rsrc_t f, unsigned so) const { return Buf<R>::ld(f, vob, so); }
 
-    struct Keep { int unused; };
-    static __device__ __forceinline__ void pin(Keep &) {}
     // scatter in[0..PC) to cells [c0, c0+PC) of a field where wmask bit t is set (all: every valid cell is written).
     // Z sweep, all cells written: transpose through the LDS tile and store element-wide, each wave-instruction
     // covering 64/PC whole tile rows of PC contiguous cells (full 64-byte segments).
-    __device__ __forceinline__ void store(rsrc_t f, unsigned fo, int c0, const R (&in)[PC], unsigned wmask, bool all, Keep &) const
+    __device__ __forceinline__ void store(rsrc_t f, unsigned fo, int c0, const R (&in)[PC], unsigned wmask, bool all) const
     {
         if (DIR == 2 && all && FS3D_Z_TILE_STORE) {
             constexpr int RPS = 64 / PC;                        // tile rows per store instruction
@@ -304,7 +304,7 @@ struct Chunk {
     // store of a sub-pass whose cells are all inside the line and all written (wave-uniform fast path of the O phase)
     __device__ __forceinline__ void store_plain(rsrc_t f, unsigned fo, int c0, const R (&in)[PC]) const
     {
-        if (DIR == 2 && FS3D_Z_TILE_STORE) { Keep k; store(f, fo, c0, in, 0xFFFFFFFFu, true, k); }
+        if (DIR == 2 && FS3D_Z_TILE_STORE) store(f, fo, c0, in, 0xFFFFFFFFu, true);
         else {
 #pragma unroll
             for (int t = 0; t < PC; t++) Buf<R>::st(f, vob_st, soff(c0 + t) + fo, in[t]);
@@ -384,13 +384,11 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
     volatile int *bflag = fflag + 4 * NPIECE * PIPE_NW;     // [NPIECE][NW]: backward step (h, w) is done
     if (threadIdx.x < 5 * NPIECE * PIPE_NW) fflag[threadIdx.x] = 0;
     __syncthreads();                                        // the only workgroup-wide barrier of the kernel
-#ifndef FS3D_NO_P_PRIO
     // The relay visits the waves in order, so the low waves are needed first: give them the issue slots first.
     // It also takes the waves out of lockstep (they would otherwise all wait for memory at the same time).
     if (w < 2) __builtin_amdgcn_s_setprio(3);
     else if (w < 4) __builtin_amdgcn_s_setprio(2);
     else if (w < 6) __builtin_amdgcn_s_setprio(1);
-#endif
 
     Chunk<R, DIR, CH> ck;
     ck.n = n; ck.wpc = w * Chunk<R, DIR, CH>::PC; ck.lane = lane; ck.lane_valid = l < la_len;
@@ -861,13 +859,12 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
                 }
                 return;
             }
-            typename CK::Keep keepN, keepT;
 #pragma unroll
             for (int v = 0; v < 4; v++) {
                 R xv[PC];
 #pragma unroll
                 for (int t = 0; t < PC; t++) xv[t] = v == 0 ? st1[c0 + t] : (v == 1 ? st2[c0 + t] : (v == 2 ? st3[c0 + t] : st0[c0 + t]));
-                ck.store(Lnext, v * fsb, c0, xv, seg_p, all_seg, keepN);
+                ck.store(Lnext, v * fsb, c0, xv, seg_p, all_seg);
                 if (p.merge) {
                     R tv[PC];
                     ck.load(Ltmp, (int)(v * fsb), c0, tv);
@@ -885,7 +882,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
                             if (p.merge == 2) tv[t] = (tv[t] + xv[t]) / R(2);
                         }
                     }
-                    ck.store(Ltout, v * fsb, c0, tv, 0xFFFFFFFFu, true, keepT);
+                    ck.store(Ltout, v * fsb, c0, tv, 0xFFFFFFFFu, true);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
