@@ -108,9 +108,12 @@ template <bool FASTM> __device__ __forceinline__ double divc(double x, const Div
 __device__ __forceinline__ DivC<float> mkdiv(float y) { return {y, recip_refined(y)}; }
 __device__ __forceinline__ DivC<double> mkdiv(double y) { return {y, 0.0}; }
 // one cell of the forward chain with the division core: c' = c/den, d' = num/den share the reciprocal of den
+// GUARD_DEN: U, V and W divide by the same den values, the first of them checks; c is checked once, in the P phase
+template <bool GUARD_DEN>
 __device__ __forceinline__ void chain_core(float c, float num, float den, float &cp, float &dp, DivGuard &ok)
 {
-    ok.den(den); ok.num(c); ok.num(num);
+    if (GUARD_DEN) ok.den(den);
+    ok.num(num);
     const float r = recip_refined(den);
     float qc = c * r, qd = num * r;
     float rc = __builtin_fmaf(-den, qc, c), rd = __builtin_fmaf(-den, qd, num);
@@ -118,6 +121,7 @@ __device__ __forceinline__ void chain_core(float c, float num, float den, float 
     rc = __builtin_fmaf(-den, qc, c); rd = __builtin_fmaf(-den, qd, num);
     cp = __builtin_fmaf(rc, r, qc); dp = __builtin_fmaf(rd, r, qd);
 }
+template <bool GUARD_DEN>
 __device__ __forceinline__ void chain_core(double c, double num, double den, double &cp, double &dp, DivGuard &) { cp = c / den; dp = num / den; }
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -511,6 +515,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
                     hi_ = hi_edge ? e_hi : hi_;
                 } else { lo_ = l_lo[t]; hi_ = l_hi[t]; }
                 q[t] = divc<FM>(gS[t], dS, ok);                 // temp->Vs / (2*ds)
+                if (FM) { ok.num(q[t] - p.vis_v); ok.num(q[t] - p.vis_t); }   // the numerators c = q - vis of the forward passes
                 x2[t] = divc<FM>(hi_ - lo_, dM2, ok);
                 if (FM && (t & 1) == 1) SB;
             }
@@ -726,7 +731,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
                 const R d = DREAD;                                                                        \
                 const R den = b - a * cp;                                                                 \
                 const R num = d - dp * a;                                                                 \
-                if (FM) chain_core(c, num, den, cp, dp, ok);                                              \
+                if (FM) chain_core<VAR == 3 || VAR == 0>(c, num, den, cp, dp, ok);                        \
                 else { cp = c / den; dp = num / den; }                                                    \
                 DWRITE;                                                                                   \
                 CWRITE;                                                                                   \
