@@ -16,6 +16,19 @@ __device__ __forceinline__ float div_fast(float x, float y)
     rem = __builtin_fmaf(-y, q, x);
     return __builtin_fmaf(rem, r, q);
 }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 div_fast2(f32x2 x, float y)
+{
+    float r = __builtin_amdgcn_rcpf(y);
+    const float e = __builtin_fmaf(-y, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    const f32x2 ny = {-y, -y}, rr = {r, r};
+    f32x2 q = x * rr;
+    f32x2 rem = __builtin_elementwise_fma(ny, q, x);
+    q = __builtin_elementwise_fma(rem, rr, q);
+    rem = __builtin_elementwise_fma(ny, q, x);
+    return __builtin_elementwise_fma(rem, rr, q);
+}
 template <int MODE>
 __global__ void __launch_bounds__(512, 2) k(const float *in, float *out, unsigned long long *cyc, float y0)
 {
@@ -33,6 +46,7 @@ __global__ void __launch_bounds__(512, 2) k(const float *in, float *out, unsigne
             if (MODE == 0) x[t] = x[t] / y;
             if (MODE == 1) x[t] = div_fast(x[t], y);
             if (MODE == 2) x[t] = x[t] * y;
+            if (MODE == 3 && (t & 1) == 0) { f32x2 v = {x[t], x[t + 1]}; v = div_fast2(v, y); x[t] = v.x; x[t + 1] = v.y; }
         }
         asm volatile("" : "+v"(y));
     }
@@ -69,5 +83,6 @@ int main()
     run<0>("IEEE division (compiler)", in, out, cyc);
     run<1>("rcp + 7 fma (no scaling)", in, out, cyc);
     run<2>("multiply", in, out, cyc);
+    run<3>("packed: rcp + 5 pk ops per 2", in, out, cyc);
     return 0;
 }
