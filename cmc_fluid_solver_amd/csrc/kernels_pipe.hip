@@ -30,9 +30,6 @@
 #include "fs3d_rows.h"
 
 #define PIPE_NW 8
-#ifndef FS3D_ILP_MASK
-#define FS3D_ILP_MASK 3     // division cores in flight between scheduling barriers of the P phase: mask + 1 cells
-#endif
 #ifndef FS3D_Z_TILE_STORE
 #define FS3D_Z_TILE_STORE 1   // Z sweep: scatter through the LDS tile in whole 64-byte row pieces
 #endif
@@ -328,7 +325,7 @@ struct Chunk {
             const R nxt = t == PC - 1 ? a_hi : a[t == PC - 1 ? t : t + 1];
             a[t] = divc<FASTM>(nxt - prev, two_ds, ok);
             prev = cur;
-            if (FASTM && (t & FS3D_ILP_MASK) == FS3D_ILP_MASK) __builtin_amdgcn_sched_barrier(0);   // the core has no VCC to serialise it: bound the overlap
+            if (FASTM && (t & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // the core has no VCC to serialise it: bound the overlap
         }
     }
 };
@@ -520,7 +517,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
                 q[t] = divc<FM>(gS[t], dS, ok);                 // temp->Vs / (2*ds)
                 if (FM) { ok.num(q[t] - p.vis_v); ok.num(q[t] - p.vis_t); }   // the numerators c = q - vis of the forward passes
                 x2[t] = divc<FM>(hi_ - lo_, dM2, ok);
-                if (FM && (t & (FS3D_ILP_MASK >> 1)) == (FS3D_ILP_MASK >> 1)) SB;
+                if (FM && (t & 1) == 1) SB;
             }
             CK::template deriv_inplace<FM>(gS, rS.lo, rS.hi, dS, ok);
             SB;
@@ -534,7 +531,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
                 ck.template land<false>(rP, x1);
                 ck.template land<false>(rM, c);
 #pragma unroll
-                for (int t = 0; t < PC; t++) { x1[t] = divc<FM>(x1[t] - c[t], dM1, ok); if (FM && (t & FS3D_ILP_MASK) == FS3D_ILP_MASK) SB; }
+                for (int t = 0; t < PC; t++) { x1[t] = divc<FM>(x1[t] - c[t], dM1, ok); if (FM && (t & 3) == 3) SB; }
             }
             SB;
             // I4: second other velocity component
@@ -590,7 +587,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
                 R cT[PC];
                 ck.template land<false>(rCT, cT);
 #pragma unroll
-                for (int t = 0; t < PC; t++) { myD[(c0 + t) * 64] = divc<FM>(cT[t] * R(3), dDt, ok) + acc[t]; if (FM && (t & FS3D_ILP_MASK) == FS3D_ILP_MASK) SB; }   // T right-hand side -> LDS
+                for (int t = 0; t < PC; t++) { myD[(c0 + t) * 64] = divc<FM>(cT[t] * R(3), dDt, ok) + acc[t]; if (FM && (t & 3) == 3) SB; }   // T right-hand side -> LDS
             }
             SB;
             ck.template issue<false, false>(Lcur, (int)fsb, c0, rC1);
@@ -599,7 +596,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
                 R cV[PC];
                 ck.template land<false>(rC0, cV);
 #pragma unroll
-                for (int t = 0; t < PC; t++) { R d = divc<FM>(cV[t] * R(3), dDt, ok); if (DIR == 0) d = d - gT[t]; st1[c0 + t] = d; if (FM && (t & FS3D_ILP_MASK) == FS3D_ILP_MASK) SB; }
+                for (int t = 0; t < PC; t++) { R d = divc<FM>(cV[t] * R(3), dDt, ok); if (DIR == 0) d = d - gT[t]; st1[c0 + t] = d; if (FM && (t & 3) == 3) SB; }
             }
             SB;
             ck.template issue<false, false>(Lcur, (int)(2 * fsb), c0, rC2);
@@ -608,14 +605,14 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
                 R cV[PC];
                 ck.template land<false>(rC1, cV);
 #pragma unroll
-                for (int t = 0; t < PC; t++) { R d = divc<FM>(cV[t] * R(3), dDt, ok); if (DIR == 1) d = d - gT[t]; st2[c0 + t] = d; if (FM && (t & FS3D_ILP_MASK) == FS3D_ILP_MASK) SB; }
+                for (int t = 0; t < PC; t++) { R d = divc<FM>(cV[t] * R(3), dDt, ok); if (DIR == 1) d = d - gT[t]; st2[c0 + t] = d; if (FM && (t & 3) == 3) SB; }
             }
             SB;
             {
                 R cV[PC];
                 ck.template land<false>(rC2, cV);
 #pragma unroll
-                for (int t = 0; t < PC; t++) { R d = divc<FM>(cV[t] * R(3), dDt, ok); if (DIR == 2) d = d - gT[t]; st3[c0 + t] = d; if (FM && (t & FS3D_ILP_MASK) == FS3D_ILP_MASK) SB; }
+                for (int t = 0; t < PC; t++) { R d = divc<FM>(cV[t] * R(3), dDt, ok); if (DIR == 2) d = d - gT[t]; st3[c0 + t] = d; if (FM && (t & 3) == 3) SB; }
             }
 #pragma unroll
             for (int t = 0; t < PC; t++) st0[c0 + t] = q[t];
