@@ -448,11 +448,36 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
     typedef Chunk<R, DIR, CH> CK;
     constexpr int PC = CK::PC;
     {
-        // cell codes of the whole chunk
+        // cell codes of the whole chunk: every load in flight before the first is decoded (the decode chain would otherwise
+        // be scheduled load by load, CH memory round trips in a row)
+        int cwv[CH];
+        // Z sweep: the codes of a lane's cells are contiguous (2 bytes each): 8 per 16-byte load where the piece lies
+        // inside the line, instead of one 64-row gather per cell
+        constexpr int CPV = 8;                                   // codes per 16-byte load
+        bool vec_codes = DIR == 2 && PC % CPV == 0;
+#pragma unroll
+        for (int h = 0; h < CK::NPASS; h++) vec_codes = vec_codes && ck.base(h * PC) + PC <= n;
+        if (vec_codes) {
+            u32x4 cq[CH / CPV > 0 ? CH / CPV : 1];
+#pragma unroll
+            for (int g = 0; g < CH / CPV; g++)
+                cq[g] = __builtin_amdgcn_raw_buffer_load_b128(rCode, ck.vob / (sizeof(R) / 2), ck.soff(g * CPV) / (sizeof(R) / 2), 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < CH; t++) {
+                unsigned d[4];
+                __builtin_memcpy(d, &cq[t / CPV], 16);
+                cwv[t] = (int)((d[(t % CPV) / 2] >> (16 * (t & 1))) & 0xFFFFu);
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < CH; t++)   // unconditional load, then masked arithmetically (a select would be turned back into a branch)
+                cwv[t] = __builtin_amdgcn_raw_buffer_load_b16(rCode, ck.vob / (sizeof(R) / 2), ck.soff(t) / (sizeof(R) / 2), 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int t = 0; t < CH; t++) {
-            // unconditional load, then masked arithmetically (a select would be turned back into a branch)
-            int cw = __builtin_amdgcn_raw_buffer_load_b16(rCode, ck.vob / (sizeof(R) / 2), ck.soff(t) / (sizeof(R) / 2), 0);
+            int cw = cwv[t];
             cw &= -(int)(lane_valid && ck.cell_ok(t));
             const int code = (cw >> (4 * DIR)) & 0xF;
             cpack[t >> 3] |= (unsigned)code << (4 * (t & 7));
