@@ -164,6 +164,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         sec = float(t.item())
 
+    # what a plain device-to-device copy reaches on this card (read + write bytes per second): context for `peak`
+    copy_gbps = None
+    if world == 1:
+        a = torch.empty(1 << 28, dtype=torch.float32, device="cuda"); b = torch.empty_like(a)      # 1 GiB each
+        b.copy_(a); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            b.copy_(a)
+        e1.record(); torch.cuda.synchronize()
+        copy_gbps = round(10 * 2 * a.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+        del a, b
+
     if rank == 0:
         cells = n ** 3
         esize = 4 if dtype == np.float32 else 8
@@ -191,10 +204,12 @@ def main():
                                    "outflow valve), Re 200 Pr 0.72 lambda 1.4, num_global 4, num_local 2, dt %.5g, "
                                    "UpdateBoundaries+TimeStep per step, EvalDivError every 10th step" % (n, args.dtype, dt),
                        "grid": [n, n, n], "parallelism": "x-slab x%d" % world, "sweep_kernel": args.kernel,
+                       "node_in_fraction": round(float((g.type == grids.NODE_IN).mean()), 4),
                        "final_div_error": err},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": names[k], "avg_launch_ms": round(per_launch_ms, 4),
+                         "device_copy_GBps": copy_gbps,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "per_class_ms_per_launch": {nm: round(ms_cls[j] / max(1, n_cls[j]), 4)
                                                      for j, nm in enumerate(names + ["other"])},
