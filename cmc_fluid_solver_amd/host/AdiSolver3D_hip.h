@@ -95,6 +95,9 @@ public:
     void GetLayer(FTYPE *v, double *T, int outdimx = 0, int outdimy = 0, int outdimz = 0) { chk(fs3d_get_layer(ctx_, v, T, outdimx, outdimy, outdimz)); }
     // cur layer on the host (ScalarField3D(CPU, field) copy constructor, TimeLayer3D.h:358-383)
     void DownloadCur(FTYPE *u, FTYPE *v, FTYPE *w, FTYPE *T) { chk(fs3d_download_layer(ctx_, FS3D_LAYER_CUR, u, v, w, T)); }
+    // device time per event class since EnableTiming(true): 0 sweeps Z, 1 sweeps Y, 2 sweeps X, 3 everything else
+    void EnableTiming(bool on) { chk(fs3d_enable_timing(ctx_, on ? 1 : 0)); }
+    void Timings(float ms[4], int count[4]) { chk(fs3d_last_step_timing(ctx_, ms, count)); }
     double EvalDivError() { double e = 0; chk(fs3d_eval_div_error(ctx_, FS3D_LAYER_NEXT, &e, nullptr)); return e; }
 
     double diffError = 0.0;

@@ -5,7 +5,8 @@
 //   * runs the same loop: dt = cycle length / (frames * time_steps), UpdateBoundaries + TimeStep per step with the
 //     divergence error every 10th step and on the last one, "err = ..." and the progress line per step,
 //   * writes <output prefix>_res.nc through host/NetCDF3.h every out_time_steps steps (GetLayer).
-// `transpose`, `decompose`, `blocking n`, `CSV` of the reference are accepted and ignored (backend tuning switches).
+// `transpose`, `decompose`, `blocking n` of the reference are accepted and ignored (backend tuning switches); `CSV`
+// switches the closing timing table to the reference's comma-separated form.
 // There is no CPU backend here: without a GPU the run stops with the library's error.
 // --grid-only FILE: build the grid, dump it (dims, type, bc_vel, bc_temp, vx, vy, vz, T as raw arrays) and exit
 //   without touching the GPU -- used by the CPU tests to compare the C++ loader with its Python twin.
@@ -22,7 +23,7 @@
 #include "Shape2D.h"
 
 template <typename FTYPE>
-static int run(const std::string &data, const std::string &prefix, const fs3d::Config &cfg, bool align, int device, long max_steps, const std::string &grid_only)
+static int run(const std::string &data, const std::string &prefix, const fs3d::Config &cfg, bool align, int device, long max_steps, const std::string &grid_only, bool csv)
 {
     using namespace fs3d;
     Grid3D<FTYPE> grid;
@@ -61,6 +62,7 @@ static int run(const std::string &data, const std::string &prefix, const fs3d::C
     std::vector<FTYPE> resVel((size_t)cfg.outdimx * cfg.outdimy * cfg.outdimz * 3);
     std::vector<double> resT((size_t)cfg.outdimx * cfg.outdimy * cfg.outdimz);
 
+    solver.EnableTiming(true);
     const auto t0 = std::chrono::steady_clock::now();
     double t = dt;
     long steps = 0;
@@ -82,7 +84,23 @@ static int run(const std::string &data, const std::string &prefix, const fs3d::C
         }
     }
     const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    std::printf("\n%ld steps in %.3f s: %.1f Mcells/s; %u layers in %s\n", steps, sec,
+    // the reference's Profiler table (Common/Profiler.h:90-131; events of AdiSolver3D.cpp:297-652).  The merges are part
+    // of the sweep kernels here; boundary lists, the cur->next copy and EvalDivError are the last row.
+    float ms[4]; int cnt[4];
+    solver.Timings(ms, cnt);
+    const char *ev[4] = {"SolveSegments_Z", "SolveSegments_Y", "SolveSegments_X", "Bounds+DivError"};
+    double total = 0;
+    if (csv) std::printf("\n%s,%s,%s,%s,\n", "Event Name", "Total (ms)", "Avg (ms)", "Count");
+    else std::printf("\nProfiling data node(0):\n%16s%16s%16s%16s\n", "Event Name", "Total (ms)", "Avg (ms)", "Count");
+    for (int e = 0; e < 4; e++) {
+        if (!cnt[e]) continue;
+        if (csv) std::printf("%s,%.2f,%.2f,%i,\n", ev[e], ms[e], ms[e] / cnt[e], cnt[e]);
+        else std::printf("%16s%16.2f%16.2f%16i\n", ev[e], ms[e], ms[e] / cnt[e], cnt[e]);
+        total += ms[e];
+    }
+    if (csv) std::printf("%s,%.2f,sec\n", "Overall", total / 1000);
+    else std::printf("%16s%16.2f sec\n", "Overall", total / 1000);
+    std::printf("%ld steps in %.3f s: %.1f Mcells/s; %u layers in %s\n", steps, sec,
                 (double)grid.dimx * grid.dimy * grid.dimz * steps / sec / 1e6, nc.NumRecords(), out.c_str());
     return 0;
 }
@@ -99,7 +117,7 @@ int main(int argc, char **argv)
         if (cfg.problem_dim != "3D") throw std::runtime_error("only `dimension 3D` runs are supported");
         if (cfg.in_fmt != "Shape2D") throw std::runtime_error("in_fmt " + cfg.in_fmt + ": only Shape2D inputs are supported");
         if (cfg.solver != "ADI") throw std::runtime_error("solver " + cfg.solver + " is not implemented (the reference implements ADI only)");
-        bool align = false, dbl = false;
+        bool align = false, dbl = false, csv = false;
         int device = 0;
         long max_steps = -1;
         std::string grid_only;
@@ -112,10 +130,11 @@ int main(int argc, char **argv)
             else if (s == "--steps" && a + 1 < argc) max_steps = std::atol(argv[++a]);
             else if (s == "--grid-only" && a + 1 < argc) grid_only = argv[++a];
             else if (s == "blocking") { if (a + 1 < argc) a++; }
-            // transpose, decompose, CSV: accepted, no effect
+            else if (s == "CSV") csv = true;
+            // transpose, decompose: accepted, no effect
         }
-        return dbl ? run<double>(argv[1], argv[2], cfg, align, device, max_steps, grid_only)
-                   : run<float>(argv[1], argv[2], cfg, align, device, max_steps, grid_only);
+        return dbl ? run<double>(argv[1], argv[2], cfg, align, device, max_steps, grid_only, csv)
+                   : run<float>(argv[1], argv[2], cfg, align, device, max_steps, grid_only, csv);
     } catch (std::exception &e) {
         std::fprintf(stderr, "\n\nCaught exception:\n%s\n\nTerminating...\n", e.what());     // FluidSolver3D.cpp:313-318
         return -1;
