@@ -29,7 +29,7 @@
 #include <utility>
 #include "fs3d_rows.h"
 
-#define PIPE_NW 8
+#define PIPE_NW 8             // waves per workgroup of a whole sweep; the halves of short slab pieces use fewer (NW)
 #ifndef FS3D_Z_TILE_STORE
 #define FS3D_Z_TILE_STORE 1   // Z sweep: scatter through the LDS tile in whole 64-byte row pieces
 #endif
@@ -144,7 +144,7 @@ template <> struct Buf<double> {
 
 // Geometry of one wave's chunk and the accessors for "one field of PC consecutive cells of the chunk".
 // P and O phases walk the chunk in sub-passes of PC cells so that their transient register arrays stay small.
-template <typename R, int DIR, int CH>
+template <typename R, int DIR, int CH, int NW = PIPE_NW>
 struct Chunk {
     static constexpr int VW = 16 / sizeof(R);          // elements per 16-byte vector
 #ifndef FS3D_PC_BYTES_XY
@@ -182,7 +182,7 @@ struct Chunk {
     // line: consecutive pieces of the line belong to consecutive waves (wave 2m and 2m+1 share the 128-byte lines
     // of a Z sweep and work on them in the same sub-pass), and the relays hand over every PC cells.
     // Local cell index lt in [0, CH) -> piece lt / PC, position lt % PC.
-    __device__ __forceinline__ int base(int c0) const { return (c0 / PC) * (PIPE_NW * PC) + wpc; }   // c0: first local cell of a piece
+    __device__ __forceinline__ int base(int c0) const { return (c0 / PC) * (NW * PC) + wpc; }   // c0: first local cell of a piece
     __device__ __forceinline__ int cell(int lt) const { return base(lt - lt % PC) + lt % PC; }
     // byte offset of local cell lt of lane 0, cell index clamped into the line
     __device__ __forceinline__ unsigned soff(int lt) const
@@ -338,8 +338,8 @@ struct Chunk {
 // carries of the slab below (p.carry_in) and the eliminated rows go to the HBM scratch, carries of the last cell to
 // p.carry_out; 2 backward half -- rows from the scratch, x of the slab above (p.xcarry_in), then the O phase.
 // Same operations on the same values as the whole sweep: a line cut into slabs gives the uncut line's numbers.
-template <typename R, int DIR, int CH, bool FM, int MODE = 0>
-__global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p, int n_o, int n_tiles, int *redo)
+template <typename R, int DIR, int CH, bool FM, int MODE = 0, int NW = PIPE_NW>
+__global__ void __launch_bounds__(NW * 64, 2) k_sweep_pipe(SweepParams<R> p, int n_o, int n_tiles, int *redo)
 {
     if (!FM && redo && redo[blockIdx.x] == 0) return;      // redo pass: this bundle was fine
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -372,21 +372,21 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
     const bool lo_edge = lane == 0;
 
     // LDS: [NW*CH][64] d_T / d'_T | [NW*CH][64] c'_T (P and O phases: per-wave transposition tiles) | relay
-    constexpr size_t LDS_D = (size_t)PIPE_NW * CH * 64;
+    constexpr size_t LDS_D = (size_t)NW * CH * 64;
     // Per-wave transposition tiles (Z sweep, P and O phases).  A tile must not overlap the c'_T rows of
     // ANOTHER wave: wave w starts writing its own c'_T rows in its forward turn while later waves may
     // still be building rows.  If a tile fits into the wave's own c'_T row range it lives there,
     // otherwise the tiles get a region of their own behind the c'_T rows.
-    constexpr size_t TILE = Chunk<R, DIR, CH>::TILE_ELEMS;
+    constexpr size_t TILE = Chunk<R, DIR, CH, NW>::TILE_ELEMS;
     constexpr bool TILE_IN_ROWS = TILE <= (size_t)CH * 64;
-    constexpr size_t LDS_C = (size_t)PIPE_NW * CH * 64 + (TILE_IN_ROWS ? 0 : (size_t)PIPE_NW * TILE);
+    constexpr size_t LDS_C = (size_t)NW * CH * 64 + (TILE_IN_ROWS ? 0 : (size_t)NW * TILE);
     R *ldsD = (R *)smem_raw;
     R *ldsC = ldsD + LDS_D;
     R *relay = ldsC + LDS_C;                                // 8 x 64 forward (c', d' per pass), reused 4 x 64 backward
-    constexpr int NPIECE = Chunk<R, DIR, CH>::NPASS;        // pieces per wave; relay step (h, w) = piece h of wave w
+    constexpr int NPIECE = Chunk<R, DIR, CH, NW>::NPASS;        // pieces per wave; relay step (h, w) = piece h of wave w
     volatile int *fflag = (volatile int *)(relay + 8 * 64); // [4 passes][NPIECE][NW]: forward pass k of step (h, w) is done
-    volatile int *bflag = fflag + 4 * NPIECE * PIPE_NW;     // [NPIECE][NW]: backward step (h, w) is done
-    if (threadIdx.x < 5 * NPIECE * PIPE_NW) fflag[threadIdx.x] = 0;
+    volatile int *bflag = fflag + 4 * NPIECE * NW;     // [NPIECE][NW]: backward step (h, w) is done
+    if (threadIdx.x < 5 * NPIECE * NW) fflag[threadIdx.x] = 0;
     __syncthreads();                                        // the only workgroup-wide barrier of the kernel
     // The relay visits the waves in order, so the low waves are needed first: give them the issue slots first.
     // It also takes the waves out of lockstep (they would otherwise all wait for memory at the same time).
@@ -394,8 +394,8 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
     else if (w < 4) __builtin_amdgcn_s_setprio(2);
     else if (w < 6) __builtin_amdgcn_s_setprio(1);
 
-    Chunk<R, DIR, CH> ck;
-    ck.n = n; ck.wpc = w * Chunk<R, DIR, CH>::PC; ck.lane = lane; ck.lane_valid = l < la_len;
+    Chunk<R, DIR, CH, NW> ck;
+    ck.n = n; ck.wpc = w * Chunk<R, DIR, CH, NW>::PC; ck.lane = lane; ck.lane_valid = l < la_len;
     // one cell beyond the owned range is readable where the line goes on: a neighbouring slab's ghost plane (X) or the
     // neighbouring segment of the same line
     ck.slo = ((DIR == 0 && p.ghost_lo) || (MODE != 0 && p.seg_begin > 0)) ? -1 : 0;
@@ -415,7 +415,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
     }
     ck.dimz = p.dimz;
     ck.rows_valid = la_len - tile_id * 64 < 64 ? la_len - tile_id * 64 : 64;
-    ck.tile = TILE_IN_ROWS ? ldsC + (size_t)w * CH * 64 : ldsC + (size_t)PIPE_NW * CH * 64 + (size_t)w * TILE;
+    ck.tile = TILE_IN_ROWS ? ldsC + (size_t)w * CH * 64 : ldsC + (size_t)NW * CH * 64 + (size_t)w * TILE;
     const int s0 = w * CH;                                      // first row of this wave in the LDS arrays (storage order, not line order)
     const bool lane_valid = ck.lane_valid;
     // this thread's column of the c'_T / d_T arrays: cell t of the chunk is at myX[t * 64] (immediate DS offsets)
@@ -445,7 +445,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
     STAMP(0);
 
     // ------------------------------------------------------------------ P: rows, field by field, PC cells per pass
-    typedef Chunk<R, DIR, CH> CK;
+    typedef Chunk<R, DIR, CH, NW> CK;
     constexpr int PC = CK::PC;
     {
         // cell codes of the whole chunk: every load in flight before the first is decoded (the decode chain would otherwise
@@ -679,7 +679,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
     }
     // halves: the eliminated rows travel through the HBM scratch in the bundle's own layout -- [segment][bundle][array][row of
     // this workgroup's LDS order][64 lanes] -- so that every access is a whole 64-lane row whatever the sweep direction
-    constexpr long long SCR_ARR = (long long)PIPE_NW * CH * 64;
+    constexpr long long SCR_ARR = (long long)NW * CH * 64;
     R *const scr = p.scr_ + (((long long)p.seg_index * p.scr_bundles + lb) * 6) * SCR_ARR + (long long)s0 * 64 + lane;
     const long long cline = (long long)o * la_len + l;      // this lane's line in the carry arrays [value][line]
     const long long cpitch = p.carry_pitch;                 // lines per value row
@@ -689,7 +689,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
     // carries its own c' (U, V, W repeat the shared c'_uvw recurrence: same inputs, same operations, same
     // rounding -> identical values).  Each is a relay over the waves; wave w runs pass k in turn w + k, so
     // up to four waves (on different SIMDs) advance at the same time and the forward phase takes
-    // PIPE_NW + 3 turns of one short pass instead of PIPE_NW turns of one long one.
+    // NW + 3 turns of one short pass instead of NW turns of one long one.
     // Chain body per cell and pass, branch-free (the row kinds only steer selects):
     //   INTERIOR a = -q - vis, b = 3/dt + 2 vis, c = q - vis      (AdiSolver3D.cpp:760-762)
     //   START    a = 0,  FREE: b = 2, c = -1 ; NOSLIP: b = 1, c = 0 (ApplyBC0, :804-827)
@@ -707,7 +707,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
     STAMP(1);
     __builtin_amdgcn_s_setprio(3);     // the serial chains are latency-critical: ahead of other waves' P/O work
     if (MODE != 2) {
-    if (w > 0) flag_wait(&fflag[3 * NPIECE * PIPE_NW + w - 1]);
+    if (w > 0) flag_wait(&fflag[3 * NPIECE * NW + w - 1]);
     STAMP(2);
 #define FWD_COEF(VAR, FASTC)                                                                              \
     {                                                                                                     \
@@ -730,7 +730,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
         /* step (H, w) follows (H, w-1), or (H-1, NW-1) for w = 0: the pieces in the order of the line */ \
         R cp = R(0), dp = R(0);                                                                           \
         if (w > 0 || H > 0) {                                                                             \
-            flag_wait(&fflag[(VAR * NPIECE + (w > 0 ? H : H - 1)) * PIPE_NW + (w > 0 ? w - 1 : PIPE_NW - 1)]); \
+            flag_wait(&fflag[(VAR * NPIECE + (w > 0 ? H : H - 1)) * NW + (w > 0 ? w - 1 : NW - 1)]); \
             cp = relay[(2 * VAR) * 64 + lane]; dp = relay[(2 * VAR + 1) * 64 + lane];                     \
         } else if (MODE == 1 && p.carry_in && lane_valid) {                                               \
             /* the recurrence continues the slab below (k_xsweep_fwd's carry layout) */                  \
@@ -764,7 +764,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
             __builtin_amdgcn_sched_barrier(0);                                                            \
         }                                                                                                 \
         relay[(2 * VAR) * 64 + lane] = cp; relay[(2 * VAR + 1) * 64 + lane] = dp;                         \
-        flag_set(&fflag[(VAR * NPIECE + H) * PIPE_NW + w]);                                               \
+        flag_set(&fflag[(VAR * NPIECE + H) * NW + w]);                                               \
     }
     static_for<NPIECE>([&](auto h_c) __attribute__((always_inline)) {
         constexpr int H = decltype(h_c)::value;
@@ -787,7 +787,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
             scr[4 * SCR_ARR + t * 64] = st3[t]; scr[5 * SCR_ARR + t * 64] = myD[t * 64];
         }
         // the slab's last cell n-1: piece hl of wave wl, local cell tl
-        const int hl = (n - 1) / (PIPE_NW * PC), rl = (n - 1) - hl * (PIPE_NW * PC), wl = rl / PC, tl = hl * PC + rl % PC;
+        const int hl = (n - 1) / (NW * PC), rl = (n - 1) - hl * (NW * PC), wl = rl / PC, tl = hl * PC + rl % PC;
         if (w == wl && lane_valid) {
             R cv = R(0), d0 = R(0), d1 = R(0), d2 = R(0);
 #pragma unroll
@@ -819,8 +819,8 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
         constexpr int H = NPIECE - 1 - decltype(hr_c)::value;   // pieces from the end of the line to its start
         // step (H, w) follows (H, w+1), or (H+1, 0) for the last wave
         R x[4] = {R(0), R(0), R(0), R(0)};
-        if (w < PIPE_NW - 1 || H < NPIECE - 1) {
-            flag_wait(&bflag[(w < PIPE_NW - 1 ? H : H + 1) * PIPE_NW + (w < PIPE_NW - 1 ? w + 1 : 0)]);
+        if (w < NW - 1 || H < NPIECE - 1) {
+            flag_wait(&bflag[(w < NW - 1 ? H : H + 1) * NW + (w < NW - 1 ? w + 1 : 0)]);
             x[0] = relay[0 * 64 + lane]; x[1] = relay[1 * 64 + lane];
             x[2] = relay[2 * 64 + lane]; x[3] = relay[3 * 64 + lane];
         } else if (MODE == 2 && p.xcarry_in && lane_valid) {
@@ -840,7 +840,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_sweep_pipe(SweepParams<R> p
         }
         relay[0 * 64 + lane] = x[0]; relay[1 * 64 + lane] = x[1];
         relay[2 * 64 + lane] = x[2]; relay[3 * 64 + lane] = x[3];
-        flag_set(&bflag[H * PIPE_NW + w]);
+        flag_set(&bflag[H * NW + w]);
         if (MODE == 2 && H == 0 && w == 0 && p.xcarry_out && lane_valid) {
             p.xcarry_out[0 * cpitch + cline] = x[0]; p.xcarry_out[1 * cpitch + cline] = x[1];
             p.xcarry_out[2 * cpitch + cline] = x[2]; p.xcarry_out[3 * cpitch + cline] = x[3];
@@ -1003,21 +1003,21 @@ static bool pipe_scratch(fs3d_ctx *c, size_t elems)
     return true;
 }
 
-template <typename R, int DIR, int CH>
+template <typename R, int DIR, int CH, int NW = PIPE_NW>
 static bool launch_half(fs3d_ctx *c, SweepParams<R> p, int half, int b0, int b1)
 {
     constexpr bool HAS_FM = std::is_same<R, float>::value;
     const int la_len = DIR == 2 ? p.dimy : p.dimz;
     const int n_o = DIR == 0 ? p.dimy : p.dimx, n_tiles = (la_len + 63) / 64, grid = b1 - b0;
-    if (DIR == 2 && p.dimz % Chunk<R, DIR, CH>::VW != 0) { c->err = "pipe halves: dimz is not a multiple of the 16-byte vector"; return false; }
-    const size_t tile = Chunk<R, DIR, CH>::TILE_ELEMS;
-    const size_t lds_c = (size_t)PIPE_NW * CH * 64 + (tile <= (size_t)CH * 64 ? 0 : (size_t)PIPE_NW * tile);
-    const size_t lds = ((size_t)PIPE_NW * CH * 64 + lds_c + 8 * 64) * sizeof(R) + 5 * Chunk<R, DIR, CH>::NPASS * PIPE_NW * sizeof(int);
+    if (DIR == 2 && p.dimz % Chunk<R, DIR, CH, NW>::VW != 0) { c->err = "pipe halves: dimz is not a multiple of the 16-byte vector"; return false; }
+    const size_t tile = Chunk<R, DIR, CH, NW>::TILE_ELEMS;
+    const size_t lds_c = (size_t)NW * CH * 64 + (tile <= (size_t)CH * 64 ? 0 : (size_t)NW * tile);
+    const size_t lds = ((size_t)NW * CH * 64 + lds_c + 8 * 64) * sizeof(R) + 5 * Chunk<R, DIR, CH, NW>::NPASS * NW * sizeof(int);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)k_sweep_pipe<R, DIR, CH, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { c->err = std::string("pipe halves: hipFuncSetAttribute: ") + hipGetErrorString(hipGetLastError()); return false; }
-        if (hipFuncSetAttribute((const void *)k_sweep_pipe<R, DIR, CH, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
-        if (HAS_FM && hipFuncSetAttribute((const void *)k_sweep_pipe<R, DIR, CH, HAS_FM, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+        if (hipFuncSetAttribute((const void *)k_sweep_pipe<R, DIR, CH, false, 1, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { c->err = std::string("pipe halves: hipFuncSetAttribute: ") + hipGetErrorString(hipGetLastError()); return false; }
+        if (hipFuncSetAttribute((const void *)k_sweep_pipe<R, DIR, CH, false, 2, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+        if (HAS_FM && hipFuncSetAttribute((const void *)k_sweep_pipe<R, DIR, CH, HAS_FM, 1, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
         attr_set = true;
     }
     if (grid <= 0) return true;
@@ -1032,13 +1032,13 @@ static bool launch_half(fs3d_ctx *c, SweepParams<R> p, int half, int b0, int b1)
                 if (hipMemsetAsync(c->redo, 0, (size_t)cap * sizeof(int), c->stream) != hipSuccess) return false;
                 c->redo_cap = cap;
             }
-            hipLaunchKernelGGL((k_sweep_pipe<R, DIR, CH, HAS_FM, 1>), dim3((unsigned)grid), dim3(PIPE_NW * 64), lds, c->stream, p, n_o, n_tiles, c->redo);
-            hipLaunchKernelGGL((k_sweep_pipe<R, DIR, CH, false, 1>), dim3((unsigned)grid), dim3(PIPE_NW * 64), lds, c->stream, p, n_o, n_tiles, c->redo);
+            hipLaunchKernelGGL((k_sweep_pipe<R, DIR, CH, HAS_FM, 1, NW>), dim3((unsigned)grid), dim3(NW * 64), lds, c->stream, p, n_o, n_tiles, c->redo);
+            hipLaunchKernelGGL((k_sweep_pipe<R, DIR, CH, false, 1, NW>), dim3((unsigned)grid), dim3(NW * 64), lds, c->stream, p, n_o, n_tiles, c->redo);
         } else {
-            hipLaunchKernelGGL((k_sweep_pipe<R, DIR, CH, false, 1>), dim3((unsigned)grid), dim3(PIPE_NW * 64), lds, c->stream, p, n_o, n_tiles, (int *)nullptr);
+            hipLaunchKernelGGL((k_sweep_pipe<R, DIR, CH, false, 1, NW>), dim3((unsigned)grid), dim3(NW * 64), lds, c->stream, p, n_o, n_tiles, (int *)nullptr);
         }
     } else {
-        hipLaunchKernelGGL((k_sweep_pipe<R, DIR, CH, false, 2>), dim3((unsigned)grid), dim3(PIPE_NW * 64), lds, c->stream, p, n_o, n_tiles, (int *)nullptr);
+        hipLaunchKernelGGL((k_sweep_pipe<R, DIR, CH, false, 2, NW>), dim3((unsigned)grid), dim3(NW * 64), lds, c->stream, p, n_o, n_tiles, (int *)nullptr);
     }
     return true;
 }
@@ -1051,19 +1051,33 @@ template <> bool xslab_pipe_supported<double>(const SweepParams<double> &p)
 {
     return p.dimz % 64 == 0 && p.dimx <= PIPE_NW * 16 && (unsigned long long)p.fstride * 4ull * sizeof(double) < (1ull << 32);
 }
-template <> bool launch_xslab_pipe<float>(fs3d_ctx *c, SweepParams<float> p, int half, int b0, int b1)
+// a slab piece of n planes keeps ceil(n / CH) waves busy: workgroups of 1, 2, 4 or 8 waves (small workgroups leave
+// room for several bundles per CU, which is what a thin slab needs)
+template <typename R, int CH>
+static bool launch_xslab_nw(fs3d_ctx *c, SweepParams<R> p, int half, int b0, int b1)
 {
     const int nbt = p.dimy * (p.dimz / 64);
-    if (!pipe_scratch<float>(c, (size_t)nbt * 6 * PIPE_NW * (p.dimx <= PIPE_NW * 16 ? 16 : 32) * 64)) return false;
+    const int nw = p.dimx <= CH ? 1 : (p.dimx <= 2 * CH ? 2 : (p.dimx <= 4 * CH ? 4 : 8));
+    if (!pipe_scratch<R>(c, (size_t)nbt * 6 * nw * CH * 64)) return false;
+    p.scr_ = (R *)c->scr; p.scr_bundles = nbt; p.seg_index = 0;
+    switch (nw) {
+    case 1: return launch_half<R, 0, CH, 1>(c, p, half, b0, b1);
+    case 2: return launch_half<R, 0, CH, 2>(c, p, half, b0, b1);
+    case 4: return launch_half<R, 0, CH, 4>(c, p, half, b0, b1);
+    default: return launch_half<R, 0, CH, 8>(c, p, half, b0, b1);
+    }
+}
+template <> bool launch_xslab_pipe<float>(fs3d_ctx *c, SweepParams<float> p, int half, int b0, int b1)
+{
+    if (p.dimx <= PIPE_NW * 16) return launch_xslab_nw<float, 16>(c, p, half, b0, b1);
+    const int nbt = p.dimy * (p.dimz / 64);
+    if (!pipe_scratch<float>(c, (size_t)nbt * 6 * PIPE_NW * 32 * 64)) return false;
     p.scr_ = (float *)c->scr; p.scr_bundles = nbt; p.seg_index = 0;
-    return p.dimx <= PIPE_NW * 16 ? launch_half<float, 0, 16>(c, p, half, b0, b1) : launch_half<float, 0, 32>(c, p, half, b0, b1);
+    return launch_half<float, 0, 32>(c, p, half, b0, b1);
 }
 template <> bool launch_xslab_pipe<double>(fs3d_ctx *c, SweepParams<double> p, int half, int b0, int b1)
 {
-    const int nbt = p.dimy * (p.dimz / 64);
-    if (!pipe_scratch<double>(c, (size_t)nbt * 6 * PIPE_NW * 16 * 64)) return false;
-    p.scr_ = (double *)c->scr; p.scr_bundles = nbt; p.seg_index = 0;
-    return launch_half<double, 0, 16>(c, p, half, b0, b1);
+    return launch_xslab_nw<double, 16>(c, p, half, b0, b1);
 }
 
 // A line of n cells, n above what one launch holds on chip (8 waves x CH cells): forward halves of the segments in
