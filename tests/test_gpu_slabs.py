@@ -174,3 +174,34 @@ def test_pipe_kernel_halves_long_slabs():
     for v in range(4):
         assert np.array_equal(ref_next[v], np.concatenate([res[r][0][v] for r in range(nranks)], axis=0)), "next %d" % v
         assert np.array_equal(ref_tmp[v], np.concatenate([res[r][1][v] for r in range(nranks)], axis=0)), "temp %d" % v
+
+
+@pytest.mark.parametrize("nranks", [2, 4])
+def test_shipped_example_on_slabs_100_steps(nranks):
+    """The reference's shipped 64^3 box_pipe case (file-driven: loader + config), 100 steps as its main loop runs them,
+    on 2 and 4 x-slabs: the err trace and the final fields equal the single-context run's (which the parity suite holds
+    against the oracle and the reference's recorded err range)."""
+    import os
+    from cmc_fluid_solver_amd import shape2d
+    inp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "inputs")
+    nodes, cfg, dt = shape2d.load_case(os.path.join(inp, "box_pipe_2D_data.txt"), os.path.join(inp, "box_pipe_2D_config.txt"))
+    params = capi.fluid_params(np.float32, cfg.Re, cfg.Pr, cfg.lam)
+    steps = 100
+
+    def loop(sv):
+        errs = []
+        for i in range(steps):
+            sv.UpdateBoundaries()
+            errs.append(sv.TimeStep(np.float32(dt), cfg.num_global, cfg.num_local, i % 10 == 0))
+        return sv.download_layer(capi.LAYER_CUR), errs
+
+    s = capi.Solver(nodes, params, np.float32)
+    ref, ref_err = loop(s)
+    s.close()
+    assert 1.0e-5 < ref_err[0] < 3.0e-5 and 1.0e-5 < ref_err[-1] < 3.0e-5     # SURVEY 8c: err 1.25e-5 ... 2.3e-5
+    grp = capi.LocalGroup(nodes, params, nranks, np.float32)
+    res = grp.run(lambda rank, sv: loop(sv))
+    grp.close()
+    for v in range(4):
+        assert np.array_equal(ref[v], np.concatenate([res[r][0][v] for r in range(nranks)], axis=0)), "field %d" % v
+    np.testing.assert_allclose(res[0][1], ref_err, rtol=1e-12)
