@@ -83,6 +83,11 @@ public:
     // multi-GPU: join the RCCL group (one process per GPU); id = 128-byte ncclUniqueId from UniqueId() on rank 0
     static void UniqueId(void *id128) { if (fs3d_comm_unique_id(id128) != FS3D_OK) throw std::runtime_error("fs3d_comm_unique_id failed"); }
     void JoinGroup(const void *id128, int rank, int nranks) { chk(fs3d_comm_init(ctx_, id128, rank, nranks)); }
+    // multi-GPU, one process (the reference's GPUplan mode, "GPU n"): one solver per slab, each driven by its own host thread,
+    // joined by an in-process group; every collective call (TimeStep, ...) is then made by all the threads
+    static void *CreateLocalGroup(int nranks) { void *g = nullptr; if (fs3d_local_group_create(nranks, &g) != FS3D_OK) throw std::runtime_error("fs3d_local_group_create failed"); return g; }
+    static void DestroyLocalGroup(void *g) { fs3d_local_group_destroy(g); }
+    void JoinLocalGroup(void *group, int rank) { chk(fs3d_comm_init_local(ctx_, group, rank)); }
 
     void UpdateBoundaries() { chk(fs3d_update_boundaries(ctx_)); }                        // AdiSolver3D.cpp:286-304
     // AdiSolver3D::TimeStep (AdiSolver3D.cpp:306-391); throws where the reference throws

@@ -1,5 +1,5 @@
 // Command-line driver: the reference's FluidSolver3D main (FluidSolver3D/FluidSolver3D.cpp:60-330) on top of
-// libfs3d_hip.so.   fs3d_run <input data> <output prefix> <config> [align] [GPU [n]] [double] [--steps N] [--grid-only FILE]
+// libfs3d_hip.so.   fs3d_run <input data> <output prefix> <config> [align] [GPU [n]] [double] [--steps N] [--same-device] [--grid-only FILE]
 //   * reads the config (host/Config.h) and a Shape2D geometry (host/Shape2D.h), prints the grid summary lines
 //     the reference prints ("Grid = X x Y x Z", "NODE_IN points = ..."),
 //   * runs the same loop: dt = cycle length / (frames * time_steps), UpdateBoundaries + TimeStep per step with the
@@ -11,6 +11,10 @@
 // --grid-only FILE: build the grid, dump it (dims, type, bc_vel, bc_temp, vx, vy, vz, T as raw arrays) and exit
 //   without touching the GPU -- used by the CPU tests to compare the C++ loader with its Python twin.
 #include <chrono>
+#include <condition_variable>
+#include <exception>
+#include <mutex>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -23,7 +27,12 @@
 #include "Shape2D.h"
 
 template <typename FTYPE>
-static int run(const std::string &data, const std::string &prefix, const fs3d::Config &cfg, bool align, int device, long max_steps, const std::string &grid_only, bool csv)
+static int run_slabs(const fs3d::Grid3D<FTYPE> &grid, const fs3d::Grid2D &g2, const std::string &prefix, const fs3d::Config &cfg, int nslabs,
+                     bool same_device, long max_steps, bool csv);
+
+template <typename FTYPE>
+static int run(const std::string &data, const std::string &prefix, const fs3d::Config &cfg, bool align, int device, long max_steps, const std::string &grid_only, bool csv,
+               int nslabs, bool same_device)
 {
     using namespace fs3d;
     Grid3D<FTYPE> grid;
@@ -45,6 +54,7 @@ static int run(const std::string &data, const std::string &prefix, const fs3d::C
         std::fclose(f);
         return 0;
     }
+    if (nslabs > 1) return run_slabs<FTYPE>(grid, g2, prefix, cfg, nslabs, same_device, max_steps, csv);
     FluidParams<FTYPE> params = cfg.useNormalizedParams ? FluidParams<FTYPE>(cfg.Re, cfg.Pr, cfg.lambda)
                                                         : FluidParams<FTYPE>(cfg.viscosity, cfg.density, cfg.R_specific, cfg.k, cfg.cv);
     AdiSolver3D<FTYPE> solver;
@@ -105,6 +115,85 @@ static int run(const std::string &data, const std::string &prefix, const fs3d::C
     return 0;
 }
 
+// "GPU n" with n > 1: the reference's single-process multi-GPU mode (GPUplan): n x-slabs (GPUplan::splitEven1D,
+// GPUplan.cpp:122-141), one solver and one host thread per slab, joined by the library's in-process group.
+// Results equal the single-GPU run's value for value.  Slab r runs on device r, or all on device 0 with --same-device.
+namespace {
+struct Barrier {
+    std::mutex m; std::condition_variable cv; int n, waiting = 0; long gen = 0;
+    explicit Barrier(int n_) : n(n_) {}
+    void wait() { std::unique_lock<std::mutex> lk(m); const long g = gen; if (++waiting == n) { waiting = 0; gen++; cv.notify_all(); } else cv.wait(lk, [&] { return gen != g; }); }
+};
+}
+
+template <typename FTYPE>
+static int run_slabs(const fs3d::Grid3D<FTYPE> &grid, const fs3d::Grid2D &g2, const std::string &prefix, const fs3d::Config &cfg, int nslabs,
+                     bool same_device, long max_steps, bool csv)
+{
+    using namespace fs3d;
+    FluidParams<FTYPE> params = cfg.useNormalizedParams ? FluidParams<FTYPE>(cfg.Re, cfg.Pr, cfg.lambda)
+                                                        : FluidParams<FTYPE>(cfg.viscosity, cfg.density, cfg.R_specific, cfg.k, cfg.cv);
+    const double length = g2.duration, dt = length / (1 * cfg.time_steps), finaltime = length * cfg.cycles;
+    const std::string out = prefix + "_res.nc";
+    NetCDF3Writer nc;
+    const float bbox[6] = {g2.bbox[0], g2.bbox[1], 0.0f, g2.bbox[2], g2.bbox[3], (float)cfg.depth};
+    nc.Create(out, bbox, dt * cfg.out_time_steps, finaltime, cfg.outdimx, cfg.outdimy, cfg.outdimz, cfg.out_vars);
+    const size_t ncell = (size_t)grid.dimx * grid.dimy * grid.dimz, plane = (size_t)grid.dimy * grid.dimz;
+    std::vector<FTYPE> fullV(ncell * 3), resVel((size_t)cfg.outdimx * cfg.outdimy * cfg.outdimz * 3);
+    std::vector<double> fullT(ncell), resT((size_t)cfg.outdimx * cfg.outdimy * cfg.outdimz);
+    void *group = AdiSolver3D<FTYPE>::CreateLocalGroup(nslabs);
+    Barrier bar(nslabs);
+    std::vector<std::exception_ptr> errs(nslabs);
+    std::vector<std::thread> th;
+    long steps_done = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int r = 0; r < nslabs; r++)
+        th.emplace_back([&, r] {
+            try {
+                const int q = grid.dimx / nslabs, rem = grid.dimx % nslabs;
+                const int x0 = r * q + std::min(r, rem), x1 = x0 + q + (r < rem ? 1 : 0);
+                AdiSolver3D<FTYPE> solver;
+                solver.Init(same_device ? 0 : r, grid, params, x0, x1);
+                solver.JoinLocalGroup(group, r);
+                if (r == 0) std::printf("Slabs: %d x-slabs of %d..%d planes\n", nslabs, q, q + (rem ? 1 : 0));
+                double t = dt;
+                long steps = 0;
+                for (int i = 0; t < finaltime && (max_steps < 0 || steps < max_steps); t += dt, i++, steps++) {
+                    solver.UpdateBoundaries();
+                    solver.TimeStep((FTYPE)dt, cfg.num_global, cfg.num_local, (i % 10 == 0) || (t + dt >= finaltime));
+                    if (r == 0) { std::printf("\rerr = %.8f, frame %i\tsubstep %i\t%i%%", solver.diffError, 0, i, (int)((float)t * 100 / (float)finaltime)); std::fflush(stdout); }
+                    if ((i % cfg.out_time_steps) == 0) {
+                        // each slab's part of `next` at full resolution (NODE_OUT stamped 99999), then FilterToArrays on the
+                        // assembled layer (TimeLayer3D.h:819-924: nearest-neighbour down-sample)
+                        solver.GetLayer(fullV.data() + 3 * (size_t)x0 * plane, fullT.data() + (size_t)x0 * plane, 0, 0, 0);
+                        bar.wait();
+                        if (r == 0) {
+                            for (int a = 0; a < cfg.outdimx; a++)
+                                for (int b = 0; b < cfg.outdimy; b++)
+                                    for (int c = 0; c < cfg.outdimz; c++) {
+                                        const size_t id = grid.Index(a * grid.dimx / cfg.outdimx, b * grid.dimy / cfg.outdimy, c * grid.dimz / cfg.outdimz);
+                                        const size_t ind = ((size_t)a * cfg.outdimy + b) * cfg.outdimz + c;
+                                        resVel[3 * ind] = fullV[3 * id]; resVel[3 * ind + 1] = fullV[3 * id + 1]; resVel[3 * ind + 2] = fullV[3 * id + 2];
+                                        resT[ind] = fullT[id];
+                                    }
+                            nc.AppendLayer(resVel.data(), resT.data());
+                        }
+                        bar.wait();
+                    }
+                }
+                if (r == 0) steps_done = steps;
+            } catch (...) { errs[r] = std::current_exception(); }
+        });
+    for (auto &t : th) t.join();
+    AdiSolver3D<FTYPE>::DestroyLocalGroup(group);
+    for (auto &e : errs) if (e) std::rethrow_exception(e);
+    const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    (void)csv;
+    std::printf("\n%ld steps in %.3f s: %.1f Mcells/s; %u layers in %s\n", steps_done, sec,
+                (double)grid.dimx * grid.dimy * grid.dimz * steps_done / sec / 1e6, nc.NumRecords(), out.c_str());
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     if (argc < 4) {
@@ -117,14 +206,16 @@ int main(int argc, char **argv)
         if (cfg.problem_dim != "3D") throw std::runtime_error("only `dimension 3D` runs are supported");
         if (cfg.in_fmt != "Shape2D") throw std::runtime_error("in_fmt " + cfg.in_fmt + ": only Shape2D inputs are supported");
         if (cfg.solver != "ADI") throw std::runtime_error("solver " + cfg.solver + " is not implemented (the reference implements ADI only)");
-        bool align = false, dbl = false, csv = false;
+        bool align = false, dbl = false, csv = false, same_device = false;
+        int nslabs = 1;
         int device = 0;
         long max_steps = -1;
         std::string grid_only;
         for (int a = 4; a < argc; a++) {
             const std::string s = argv[a];
             if (s == "align") align = true;
-            else if (s == "GPU") { if (a + 1 < argc && std::atoi(argv[a + 1]) > 0) a++; }     // the reference's "GPU n": n devices of one process
+            else if (s == "GPU") { if (a + 1 < argc && std::atoi(argv[a + 1]) > 0) nslabs = std::atoi(argv[++a]); }   // the reference's "GPU n": n devices of one process
+            else if (s == "--same-device") same_device = true;
             else if (s == "double") dbl = true;
             else if (s == "--device" && a + 1 < argc) device = std::atoi(argv[++a]);
             else if (s == "--steps" && a + 1 < argc) max_steps = std::atol(argv[++a]);
@@ -133,8 +224,8 @@ int main(int argc, char **argv)
             else if (s == "CSV") csv = true;
             // transpose, decompose: accepted, no effect
         }
-        return dbl ? run<double>(argv[1], argv[2], cfg, align, device, max_steps, grid_only, csv)
-                   : run<float>(argv[1], argv[2], cfg, align, device, max_steps, grid_only, csv);
+        return dbl ? run<double>(argv[1], argv[2], cfg, align, device, max_steps, grid_only, csv, nslabs, same_device)
+                   : run<float>(argv[1], argv[2], cfg, align, device, max_steps, grid_only, csv, nslabs, same_device);
     } catch (std::exception &e) {
         std::fprintf(stderr, "\n\nCaught exception:\n%s\n\nTerminating...\n", e.what());     // FluidSolver3D.cpp:313-318
         return -1;

@@ -125,3 +125,24 @@ def test_driver_runs_the_shipped_example(driver, tmp_path):
         np.testing.assert_array_equal(f.variables["T"][r], T)
     np.testing.assert_allclose(f.variables["time"][:], np.arange(len(layers)) * dt * cfg.out_time_steps)
     f.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nslabs", [2, 3])
+def test_driver_gpu_n_mode_equals_single_gpu(driver, nslabs, tmp_path):
+    """`GPU n` (the reference's one-process multi-GPU mode): n x-slabs, one host thread each, in-process transport; all
+    slabs on device 0 here (--same-device).  err prints and result file equal the single-GPU run's."""
+    from scipy.io import netcdf_file
+    data, cfgf = (os.path.join(INPUTS, f) for f in CASES["non_uniform_pipe"])
+    outs = {}
+    for tag, extra in (("one", ["GPU"]), ("slabs", ["GPU", str(nslabs), "--same-device"])):
+        prefix = str(tmp_path / tag)
+        out = subprocess.run([driver, data, prefix, cfgf, "align"] + extra + ["--steps", "21"], check=True, capture_output=True, text=True).stdout
+        f = netcdf_file(prefix + "_res.nc", "r", mmap=False)
+        outs[tag] = ([float(x) for x in re.findall(r"err = ([0-9.]+),", out)],
+                     {v: np.array(f.variables[v][:]) for v in ("u", "v", "w", "T", "time")})
+        f.close()
+    assert len(outs["one"][0]) == 21 and outs["one"][0] == outs["slabs"][0]
+    for v in ("u", "v", "w", "T", "time"):
+        assert outs["one"][1][v].shape[0] == 3
+        np.testing.assert_array_equal(outs["one"][1][v], outs["slabs"][1][v])
