@@ -25,6 +25,7 @@
 // workgroup for 256 fp32 cells).  The halves (MODE 1/2) pass them through an HBM scratch instead: lines of any
 // length, x-slabs of a multi-GPU run.
 #include <algorithm>
+#include <atomic>
 #include <type_traits>
 #include <utility>
 #include "fs3d_rows.h"
@@ -935,13 +936,15 @@ static bool launch_one(fs3d_ctx *c, const SweepParams<R> &p)
     const size_t lds = ((size_t)PIPE_NW * CH * 64 + lds_c + 8 * 64) * sizeof(R) + 5 * Chunk<R, DIR, CH>::NPASS * PIPE_NW * sizeof(int);
     const int grid = n_o * n_tiles;
     constexpr bool HAS_FM = std::is_same<R, float>::value;
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the attribute is per device: one bit per device id (several devices can be driven from one process)
+    static std::atomic<unsigned long long> attr_set{0};
+    const unsigned long long dev_bit = 1ull << (c->device & 63);
+    if (!(attr_set.load() & dev_bit)) {
         if (hipFuncSetAttribute((const void *)k_sweep_pipe<R, DIR, CH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return false;
         if (HAS_FM && hipFuncSetAttribute((const void *)k_sweep_pipe<R, DIR, CH, HAS_FM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return false;
-        attr_set = true;
+        attr_set.fetch_or(dev_bit);
     }
     if (HAS_FM && p.fast_div) {
         // division core first; the full-division instance right behind it redoes the bundles that asked for it
@@ -1013,12 +1016,14 @@ static bool launch_half(fs3d_ctx *c, SweepParams<R> p, int half, int b0, int b1)
     const size_t tile = Chunk<R, DIR, CH, NW>::TILE_ELEMS;
     const size_t lds_c = (size_t)NW * CH * 64 + (tile <= (size_t)CH * 64 ? 0 : (size_t)NW * tile);
     const size_t lds = ((size_t)NW * CH * 64 + lds_c + 8 * 64) * sizeof(R) + 5 * Chunk<R, DIR, CH, NW>::NPASS * NW * sizeof(int);
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the attribute is per device: one bit per device id (several devices can be driven from one process)
+    static std::atomic<unsigned long long> attr_set{0};
+    const unsigned long long dev_bit = 1ull << (c->device & 63);
+    if (!(attr_set.load() & dev_bit)) {
         if (hipFuncSetAttribute((const void *)k_sweep_pipe<R, DIR, CH, false, 1, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { c->err = std::string("pipe halves: hipFuncSetAttribute: ") + hipGetErrorString(hipGetLastError()); return false; }
         if (hipFuncSetAttribute((const void *)k_sweep_pipe<R, DIR, CH, false, 2, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
         if (HAS_FM && hipFuncSetAttribute((const void *)k_sweep_pipe<R, DIR, CH, HAS_FM, 1, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
-        attr_set = true;
+        attr_set.fetch_or(dev_bit);
     }
     if (grid <= 0) return true;
     p.bundle0 = b0;
