@@ -481,3 +481,24 @@ def test_lines_longer_than_one_launch_holds(built, dims, dtype):
         e = s.TimeStep(DT, 4, 2, True); rc, eo = o.time_step(DT, 4, 2, True)
         assert e == pytest.approx(eo, rel=1e-12)
     assert_layers_equal(s, o, capi.LAYER_CUR, O.L_CUR, "cur")
+
+
+def test_full_size_50_steps_kernels_agree(built):
+    """256^3 fp32 box from rest, 50 time steps (1200 sweeps): the pipelined kernel (division core, its per-bundle redo while
+    the far field still holds values between 0 and 2^-100, fused merges) against the thread-per-line kernel with
+    unfused merges -- err trace and final fields identical."""
+    g = grids.box(256, h=1.0 / 255)
+    params = capi.fluid_params(np.float32, *PARAMS)
+    res = []
+    for kernel, fuse in ((capi.SWEEP_PIPE, 1), (capi.SWEEP_LINE, 0)):
+        s = capi.Solver(g, params, np.float32)
+        s.set_option(capi.OPT_SWEEP_KERNEL, kernel); s.set_option(capi.OPT_FUSE_MERGE, fuse)
+        errs = []
+        for i in range(50):
+            s.UpdateBoundaries()
+            errs.append(s.TimeStep(0.1, 4, 2, i % 10 == 0))
+        res.append((s.download_layer(capi.LAYER_CUR), errs))
+        s.close()
+    assert res[0][1] == res[1][1]
+    for v in range(4):
+        assert np.array_equal(res[0][0][v], res[1][0][v]), "field %d" % v
