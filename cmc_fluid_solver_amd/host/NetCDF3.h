@@ -102,6 +102,7 @@ public:
                                      text("history", "created by using cmc-fluid-solver"), text("description", "Test data"), text("platform", "Model")};
         // sizes and offsets: fixed variables first, then the records
         const uint64_t cells = (uint64_t)outdimx * outdimy * outdimz;
+        if (cells * 8 >= 0xFFFFFFFCull) throw std::runtime_error("output grid too large for one netCDF classic record variable (>= 4 GiB per layer)");
         for (Var &v : vars_) v.vsize = v.record ? (v.dims.size() == 1 ? 8 : cells * 8) : (uint64_t)dimlen[v.dims[0]] * 4;
         for (Var &v : vars_) v.vsize = (v.vsize + 3) / 4 * 4;
         uint64_t off = header(dimlen, dimname, gatts).size();
