@@ -48,8 +48,13 @@ __device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make
 // producer publishes its data, then the flag; the consumer polls the flag, then reads.  DS operations of a wave
 // execute in order; the fences keep the compiler from moving accesses across the flag.  The poll is bounded:
 // a lost hand-off ends in wrong numbers (caught by the parity tests), never in a hung GPU.
-__device__ __forceinline__ void flag_wait(volatile int *f)
+// The flags are accessed through explicit LDS (address space 3) pointers: a volatile access through a generic
+// pointer is compiled to a FLAT instruction with system-scope cache bits and a vmcnt(0) wait behind it, several
+// times the latency of the ds_read / ds_write these turn into.
+typedef __attribute__((address_space(3))) volatile int lds_flag_t;
+__device__ __forceinline__ void flag_wait(volatile int *f_)
 {
+    lds_flag_t *f = (lds_flag_t *)f_;
     int guard = 0;
     while (__builtin_amdgcn_readfirstlane(*f) == 0) {
         __builtin_amdgcn_s_sleep(1);
@@ -57,8 +62,9 @@ __device__ __forceinline__ void flag_wait(volatile int *f)
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
-__device__ __forceinline__ void flag_set(volatile int *f)
+__device__ __forceinline__ void flag_set(volatile int *f_)
 {
+    lds_flag_t *f = (lds_flag_t *)f_;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     *f = 1;
 }
@@ -387,7 +393,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_sweep_pipe(SweepParams<R> p, int
     constexpr int NPIECE = Chunk<R, DIR, CH, NW>::NPASS;        // pieces per wave; relay step (h, w) = piece h of wave w
     volatile int *fflag = (volatile int *)(relay + 8 * 64); // [4 passes][NPIECE][NW]: forward pass k of step (h, w) is done
     volatile int *bflag = fflag + 4 * NPIECE * NW;     // [NPIECE][NW]: backward step (h, w) is done
-    if (threadIdx.x < 5 * NPIECE * NW) fflag[threadIdx.x] = 0;
+    if (threadIdx.x < 5 * NPIECE * NW) ((lds_flag_t *)fflag)[threadIdx.x] = 0;
     __syncthreads();                                        // the only workgroup-wide barrier of the kernel
     // The relay visits the waves in order, so the low waves are needed first: give them the issue slots first.
     // It also takes the waves out of lockstep (they would otherwise all wait for memory at the same time).
@@ -747,9 +753,8 @@ __global__ void __launch_bounds__(NW * 64, 2) k_sweep_pipe(SweepParams<R> p, int
                otherwise the coefficients of the whole chunk are computed up front (96 live registers) */ \
             asm volatile("" : "+v"(cp), "+v"(dp), "+v"(st0[g]), "+v"(st0[g + 1]), "+v"(st0[g + 2]), "+v"(st0[g + 3])); \
             /* only the coefficients differ between the two arms; the chain below is common code */      \
-            if (((umask >> g) & 0xFu) == 0xFu) {                                                          \
-                _Pragma("unroll") for (int i = 0; i < 4; i++) FWD_COEF(VAR, true)                         \
-            } else {                                                                                      \
+            _Pragma("unroll") for (int i = 0; i < 4; i++) FWD_COEF(VAR, true)                             \
+            if (((umask >> g) & 0xFu) != 0xFu) {          /* rare: the interior values are overwritten in place */ \
                 _Pragma("unroll") for (int i = 0; i < 4; i++) FWD_COEF(VAR, false)                        \
             }                                                                                             \
             _Pragma("unroll") for (int t = g; t < g + 4; t++) {                                           \
@@ -769,7 +774,10 @@ __global__ void __launch_bounds__(NW * 64, 2) k_sweep_pipe(SweepParams<R> p, int
     }
     static_for<NPIECE>([&](auto h_c) __attribute__((always_inline)) {
         constexpr int H = decltype(h_c)::value;
-        FWD_PASS(3, H, myD[t * 64], myD[t * 64] = dp, myC[t * 64] = cp)
+        R dTv[PC];                                             // T right-hand sides of the piece: out of the LDS before the wait for the turn
+#pragma unroll
+        for (int t = 0; t < PC; t++) dTv[t] = myD[(H * PC + t) * 64];
+        FWD_PASS(3, H, dTv[t - H * PC], myD[t * 64] = dp, myC[t * 64] = cp)
         FWD_PASS(0, H, st1[t], st1[t] = dp, (void)0)
         FWD_PASS(1, H, st2[t], st2[t] = dp, (void)0)
         FWD_PASS(2, H, st3[t], st3[t] = dp, st0[t] = cp)       // last pass over the cell: c'_uvw replaces q
@@ -820,6 +828,10 @@ __global__ void __launch_bounds__(NW * 64, 2) k_sweep_pipe(SweepParams<R> p, int
         constexpr int H = NPIECE - 1 - decltype(hr_c)::value;   // pieces from the end of the line to its start
         // step (H, w) follows (H, w+1), or (H+1, 0) for the last wave
         R x[4] = {R(0), R(0), R(0), R(0)};
+        // the T rows of the piece come from the LDS: requested before the wait for the turn, not inside the chain
+        R ctv[PC], e3v[PC];
+#pragma unroll
+        for (int t = 0; t < PC; t++) { ctv[t] = myC[(H * PC + t) * 64]; e3v[t] = myD[(H * PC + t) * 64]; }
         if (w < NW - 1 || H < NPIECE - 1) {
             flag_wait(&bflag[(w < NW - 1 ? H : H + 1) * NW + (w < NW - 1 ? w + 1 : 0)]);
             x[0] = relay[0 * 64 + lane]; x[1] = relay[1 * 64 + lane];
@@ -831,8 +843,8 @@ __global__ void __launch_bounds__(NW * 64, 2) k_sweep_pipe(SweepParams<R> p, int
         }
 #pragma unroll
         for (int t = (H + 1) * PC - 1; t >= H * PC; t--) {
-            const R c_v = st0[t], c_t = myC[t * 64];
-            const R e0 = st1[t], e1 = st2[t], e2 = st3[t], e3 = myD[t * 64];
+            const R c_v = st0[t], c_t = ctv[t - H * PC];
+            const R e0 = st1[t], e1 = st2[t], e2 = st3[t], e3 = e3v[t - H * PC];
             // x[num-1] = d[num-1] (Algorithms.h:34): END and SKIP rows carry c' = 0 and so do not look at x[i+1]
             x[0] = e0 - c_v * x[0]; x[1] = e1 - c_v * x[1];   // Algorithms.h:36-37
             x[2] = e2 - c_v * x[2]; x[3] = e3 - c_t * x[3];
