@@ -59,6 +59,7 @@ struct SweepParams {
     long long carry_pitch;      // lines per value row of the carry arrays
     int fast_div;               // pipe kernel, fp32: constant divisors are in the range of the division core (kernels_pipe.hip)
     int merge;                  // 0: write next only; 1: also temp_out = merged; 2: merged twice (sweep merge + global merge)
+    int store_next;             // pipe kernel, fused time step: 0 when a later local iteration overwrites `next` unread (only the merge uses x)
 };
 
 struct fs3d_ctx {

@@ -492,7 +492,8 @@ static void fill_params(fs3d_ctx *c, SweepParams<R> &p, int dir, double dt_, int
     p.b_v = 3 / dt + 2 * p.vis_v;                                    // AdiSolver3D.cpp:761
     p.b_t = 3 / dt + 2 * p.vis_t;
     p.dt = dt; p.v_T = (R)c->v_T; p.t_phi = (R)c->t_phi;
-    p.merge = merge;
+    p.merge = merge & 3;
+    p.store_next = (merge & 4) ? 0 : 1;      // merge | 4: the caller never reads this sweep's `next` (time_step_enqueue)
     p.stamps = nullptr;
     p.carry_in = nullptr; p.carry_out = nullptr; p.xcarry_in = nullptr; p.xcarry_out = nullptr; p.bundle0 = 0;
     p.seg_begin = 0; p.seg_len = 0; p.carry_pitch = c->plane; p.seg_index = 0; p.scr_bundles = 0;
@@ -791,7 +792,9 @@ static fs3d_status time_step_enqueue(fs3d_ctx *c, double dt, int G, int L, bool 
             const int plan[3][3] = {{2, bCur, bNext}, {1, bNext, bHalf}, {0, bHalf, bNext}};
             for (int d = 0; d < 3; d++)
                 for (int l = 0; l < L; l++) {
-                    const int merge = (d == 2 && l == L - 1) ? 2 : 1;
+                    // `next` of a local iteration that is not the last of its direction is overwritten by the following
+                    // one without having been read (the merge into temp is fused into the kernel): not stored
+                    const int merge = ((d == 2 && l == L - 1) ? 2 : 1) | (l < L - 1 ? 4 : 0);
                     if ((st = fs3d_comm_halo_exchange(c, bTin, 4))) return st;
                     if ((st = sweep_buffers<R>(c, plan[d][0], dt, plan[d][1], bTin, plan[d][2], bTout, merge))) return st;
                     if (bTin == bCur) { bTin = bTout; bTout = bSpare; }

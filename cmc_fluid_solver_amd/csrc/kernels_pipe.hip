@@ -885,7 +885,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_sweep_pipe(SweepParams<R> p, int
                     R xv[PC];
 #pragma unroll
                     for (int t = 0; t < PC; t++) xv[t] = v == 0 ? st1[c0 + t] : (v == 1 ? st2[c0 + t] : (v == 2 ? st3[c0 + t] : st0[c0 + t]));
-                    ck.store_plain(Lnext, v * fsb, c0, xv);
+                    if (p.store_next) ck.store_plain(Lnext, v * fsb, c0, xv);
                     if (p.merge) {
                         if (v < 3) ck.template issue<false, false>(Ltmp, (int)((v + 1) * fsb), c0, rt[(v + 1) & 1]);
                         __builtin_amdgcn_sched_barrier(0);
@@ -907,7 +907,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_sweep_pipe(SweepParams<R> p, int
                 R xv[PC];
 #pragma unroll
                 for (int t = 0; t < PC; t++) xv[t] = v == 0 ? st1[c0 + t] : (v == 1 ? st2[c0 + t] : (v == 2 ? st3[c0 + t] : st0[c0 + t]));
-                ck.store(Lnext, v * fsb, c0, xv, seg_p, all_seg);
+                if (p.store_next) ck.store(Lnext, v * fsb, c0, xv, seg_p, all_seg);
                 if (p.merge) {
                     R tv[PC];
                     ck.load(Ltmp, (int)(v * fsb), c0, tv);
