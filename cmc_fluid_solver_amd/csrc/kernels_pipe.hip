@@ -289,11 +289,25 @@ struct Chunk {
     // covering 64/PC whole tile rows of PC contiguous cells (full 64-byte segments).
     __device__ __forceinline__ void store(rsrc_t f, unsigned fo, int c0, const R (&in)[PC], unsigned wmask, bool all) const
     {
-        if (DIR == 2 && all && FS3D_Z_TILE_STORE) {
+        if (DIR == 2 && FS3D_Z_TILE_STORE) {
             constexpr int RPS = 64 / PC;                        // tile rows per store instruction
             const int col = lane % PC, rsub = lane / PC;
             R *const tcol = tile + lane * TSTRIDE;
             R *const trow = tile + (rsub * TSTRIDE + col);
+            // Not every cell written (lines off the segments, e.g. the wall lines of a box): the write masks go
+            // through the tile as well -- lane (row, col) needs bit col of row's mask.  Storing such sub-passes per
+            // lane instead (4 bytes per 1 KB row) made the `next` stores of a Z sweep cost 5x those of the other sweeps.
+            unsigned tmask = 0xFFFFFFFFu;                       // bit r: this lane's element of store instruction r is written
+            if (!all) {
+                typedef typename std::conditional<sizeof(R) == 4, unsigned, unsigned long long>::type bits_t;
+                tcol[0] = __builtin_bit_cast(R, (bits_t)wmask);
+                tmask = 0;
+#pragma unroll
+                for (int r = 0; r < PC; r++) {
+                    const unsigned m = (unsigned)__builtin_bit_cast(bits_t, trow[r * RPS * TSTRIDE - col]);
+                    tmask |= ((m >> col) & 1u) << r;
+                }
+            }
 #pragma unroll
             for (int t = 0; t < PC; t++) tcol[t] = in[t];
             const bool col_ok = base(c0) + col < n;
@@ -301,7 +315,7 @@ struct Chunk {
             for (int r = 0; r < PC; r++) {
                 const int row = r * RPS + rsub;
                 const R val = trow[r * RPS * TSTRIDE];
-                const bool ok = col_ok && row < rows_valid;
+                const bool ok = col_ok && row < rows_valid && ((tmask >> r) & 1u);
                 Buf<R>::st(f, ok ? (unsigned)(row * dimz + base(c0) + col) * (unsigned)sizeof(R) : BUF_OOB, row0 + fo, val);
             }
         } else {
