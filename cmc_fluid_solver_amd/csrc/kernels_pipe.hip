@@ -174,6 +174,8 @@ struct Chunk {
     unsigned vob;              // per-lane byte offset, clamped into the tile for lanes past the lane axis: loads are
                                // UNCONDITIONAL (a predicated load costs a branch and an s_waitcnt vmcnt(0) at its join)
     unsigned vob_st;           // vob for valid lanes, BUF_OOB for lanes past the lane axis: stores of cells known to be in the line
+    unsigned vob_live;         // vob_st, and BUF_OOB for dead lines too (see `dead` in the kernel): stores of solved values
+    bool dead, any_dead;       // this lane's whole line is neither solved nor merged / some lane of the wave is such a line
     unsigned fbytes;           // bytes of one field incl. both halo planes (descriptor range)
     int dimz, rows_valid;      // Z: row pitch (elements), number of valid tile rows
     R *tile;                   // Z: this wave's [66][PC+1] LDS tile
@@ -327,12 +329,14 @@ struct Chunk {
         }
     }
     // store of a sub-pass whose cells are all inside the line and all written (wave-uniform fast path of the O phase)
-    __device__ __forceinline__ void store_plain(rsrc_t f, unsigned fo, int c0, const R (&in)[PC]) const
+    // live_only: solved values -- nothing is written on dead lines
+    __device__ __forceinline__ void store_plain(rsrc_t f, unsigned fo, int c0, const R (&in)[PC], bool live_only = false) const
     {
-        if (DIR == 2 && FS3D_Z_TILE_STORE) store(f, fo, c0, in, 0xFFFFFFFFu, true);
+        if (DIR == 2 && FS3D_Z_TILE_STORE) store(f, fo, c0, in, dead ? 0u : 0xFFFFFFFFu, !(live_only && any_dead));
         else {
+            const unsigned vo = live_only ? vob_live : vob_st;
 #pragma unroll
-            for (int t = 0; t < PC; t++) Buf<R>::st(f, vob_st, soff(c0 + t) + fo, in[t]);
+            for (int t = 0; t < PC; t++) Buf<R>::st(f, vo, soff(c0 + t) + fo, in[t]);
         }
     }
     // central difference along the sweep, in place: a[t] <- (a[t+1] - a[t-1]) / two_ds   (TimeLayer3D.h:338-340)
@@ -407,6 +411,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_sweep_pipe(SweepParams<R> p, int
     constexpr int NPIECE = Chunk<R, DIR, CH, NW>::NPASS;        // pieces per wave; relay step (h, w) = piece h of wave w
     volatile int *fflag = (volatile int *)(relay + 8 * 64); // [4 passes][NPIECE][NW]: forward pass k of step (h, w) is done
     volatile int *bflag = fflag + 4 * NPIECE * NW;     // [NPIECE][NW]: backward step (h, w) is done
+    volatile int *live_lds = bflag + NPIECE * NW;      // [NW][2]: lanes whose line has a solved or merged cell among the wave's cells
     if (threadIdx.x < 5 * NPIECE * NW) ((lds_flag_t *)fflag)[threadIdx.x] = 0;
     __syncthreads();                                        // the only workgroup-wide barrier of the kernel
     // The relay visits the waves in order, so the low waves are needed first: give them the issue slots first.
@@ -506,10 +511,28 @@ __global__ void __launch_bounds__(NW * 64, 2) k_sweep_pipe(SweepParams<R> p, int
             if ((code & 3) != ROW_SKIP) segmask |= 1u << t;
             if ((code & 3) == ROW_INTERIOR) intmask |= 1u << t;
         }
+        // Dead lines: no cell of the line is on a segment or NODE_IN (the wall lines of a box) -- nothing the sweep
+        // computes for them is ever stored, and temp_out only receives their old temp values.  Such lanes must not
+        // keep the rest of the bundle off the fast paths: they run along with INTERIOR rows, finite garbage that
+        // stays in its lane.  Whole lines only (a dead stretch may hand its recurrence to a live segment): the
+        // waves combine what they see of each line through the LDS.  Halves see a part of the line: no dead lanes.
+        ck.dead = false; ck.any_dead = false; ck.vob_live = ck.vob_st;
+        if (MODE == 0) {
+            const unsigned long long live_w = __ballot(lane_valid && ((segmask | inmask) != 0));
+            if (lane == 0) { ((lds_flag_t *)live_lds)[2 * w] = (int)(unsigned)live_w; ((lds_flag_t *)live_lds)[2 * w + 1] = (int)(unsigned)(live_w >> 32); }
+            __syncthreads();
+            unsigned lo = 0, hi = 0;
+#pragma unroll
+            for (int i = 0; i < NW; i++) { lo |= (unsigned)((lds_flag_t *)live_lds)[2 * i]; hi |= (unsigned)((lds_flag_t *)live_lds)[2 * i + 1]; }
+            const unsigned long long live_all = ((unsigned long long)hi << 32) | lo;
+            ck.dead = lane_valid && !((live_all >> lane) & 1ull);
+            ck.any_dead = __any(ck.dead);
+            if (ck.dead) ck.vob_live = BUF_OOB;
+        }
         {
             // cells that are INTERIOR rows on every line of the bundle: AND over the lanes (lanes past the lane axis
-            // do not care).  Wave-uniform, so the fast paths below are plain scalar branches.
-            unsigned m = lane_valid ? intmask : 0xFFFFFFFFu;
+            // and dead lines do not care).  Wave-uniform, so the fast paths below are plain scalar branches.
+            unsigned m = (lane_valid && !ck.dead) ? intmask : 0xFFFFFFFFu;
 #pragma unroll
             for (int k = 1; k < 64; k <<= 1) m &= (unsigned)__shfl_xor((int)m, k, 64);
             umask = (unsigned)__builtin_amdgcn_readfirstlane((int)m);
@@ -797,7 +820,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_sweep_pipe(SweepParams<R> p, int
         FWD_PASS(2, H, st3[t], st3[t] = dp, st0[t] = cp)       // last pass over the cell: c'_uvw replaces q
     });
 #undef FWD_PASS
-    if (FM) { if (!__all(ok.plain()) && lane == 0) atomicOr(&redo[blockIdx.x], 1); }
+    if (FM) { if (!__all(ok.plain() || ck.dead) && lane == 0) atomicOr(&redo[blockIdx.x], 1); }
 #undef FWD_COEF
     STAMP(3);
     }   // MODE != 2
@@ -899,7 +922,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_sweep_pipe(SweepParams<R> p, int
                     R xv[PC];
 #pragma unroll
                     for (int t = 0; t < PC; t++) xv[t] = v == 0 ? st1[c0 + t] : (v == 1 ? st2[c0 + t] : (v == 2 ? st3[c0 + t] : st0[c0 + t]));
-                    if (p.store_next) ck.store_plain(Lnext, v * fsb, c0, xv);
+                    if (p.store_next) ck.store_plain(Lnext, v * fsb, c0, xv, true);
                     if (p.merge) {
                         if (v < 3) ck.template issue<false, false>(Ltmp, (int)((v + 1) * fsb), c0, rt[(v + 1) & 1]);
                         __builtin_amdgcn_sched_barrier(0);
@@ -907,8 +930,9 @@ __global__ void __launch_bounds__(NW * 64, 2) k_sweep_pipe(SweepParams<R> p, int
                         ck.template land<false>(rt[v & 1], tv);
 #pragma unroll
                         for (int t = 0; t < PC; t++) {
-                            tv[t] = (tv[t] + xv[t]) / R(2);                          // MergeFieldTo (TimeLayer3D.h:415-436)
-                            if (p.merge == 2) tv[t] = (tv[t] + xv[t]) / R(2);
+                            R mv = (tv[t] + xv[t]) / R(2);                           // MergeFieldTo (TimeLayer3D.h:415-436)
+                            if (p.merge == 2) mv = (mv + xv[t]) / R(2);
+                            tv[t] = ck.dead ? tv[t] : mv;                            // dead lines: the old temp value moves on
                         }
                         ck.store_plain(Ltout, v * fsb, c0, tv);
                     }
@@ -959,7 +983,7 @@ static bool launch_one(fs3d_ctx *c, const SweepParams<R> &p)
     if (DIR == 2 && p.dimz % Chunk<R, DIR, CH>::VW != 0) return false;   // Z moves whole 16-byte row pieces
     const size_t tile = Chunk<R, DIR, CH>::TILE_ELEMS;
     const size_t lds_c = (size_t)PIPE_NW * CH * 64 + (tile <= (size_t)CH * 64 ? 0 : (size_t)PIPE_NW * tile);
-    const size_t lds = ((size_t)PIPE_NW * CH * 64 + lds_c + 8 * 64) * sizeof(R) + 5 * Chunk<R, DIR, CH>::NPASS * PIPE_NW * sizeof(int);
+    const size_t lds = ((size_t)PIPE_NW * CH * 64 + lds_c + 8 * 64) * sizeof(R) + (5 * Chunk<R, DIR, CH>::NPASS + 2) * PIPE_NW * sizeof(int);
     const int grid = n_o * n_tiles;
     constexpr bool HAS_FM = std::is_same<R, float>::value;
     // the attribute is per device: one bit per device id (several devices can be driven from one process)
@@ -1041,7 +1065,7 @@ static bool launch_half(fs3d_ctx *c, SweepParams<R> p, int half, int b0, int b1)
     if (DIR == 2 && p.dimz % Chunk<R, DIR, CH, NW>::VW != 0) { c->err = "pipe halves: dimz is not a multiple of the 16-byte vector"; return false; }
     const size_t tile = Chunk<R, DIR, CH, NW>::TILE_ELEMS;
     const size_t lds_c = (size_t)NW * CH * 64 + (tile <= (size_t)CH * 64 ? 0 : (size_t)NW * tile);
-    const size_t lds = ((size_t)NW * CH * 64 + lds_c + 8 * 64) * sizeof(R) + 5 * Chunk<R, DIR, CH, NW>::NPASS * NW * sizeof(int);
+    const size_t lds = ((size_t)NW * CH * 64 + lds_c + 8 * 64) * sizeof(R) + (5 * Chunk<R, DIR, CH, NW>::NPASS + 2) * NW * sizeof(int);
     // the attribute is per device: one bit per device id (several devices can be driven from one process)
     static std::atomic<unsigned long long> attr_set{0};
     const unsigned long long dev_bit = 1ull << (c->device & 63);
