@@ -502,3 +502,59 @@ def test_full_size_50_steps_kernels_agree(built):
     assert res[0][1] == res[1][1]
     for v in range(4):
         assert np.array_equal(res[0][0][v], res[1][0][v]), "field %d" % v
+
+
+def _bars_grid():
+    """box + three solid bars that run the full length of the box, one along each axis, away from the walls: the
+    lines inside a bar have no solved and no merged cell at all (dead lines) and sit between live lines of the same
+    64-line bundle; lines that cross a bar carry two segments."""
+    n = grids.box(24, 72, 72, h=0.03)
+    solid = np.zeros(n.shape, bool)
+    solid[:, 20:25, 30:35] = True          # along x
+    solid[8:13, :, 40:45] = True           # along y
+    solid[14:19, 50:55, :] = True          # along z
+    inner = np.zeros(n.shape, bool)
+    inner[:, 21:24, 31:34] = True
+    inner[9:12, :, 41:44] = True
+    inner[15:18, 51:54, :] = True
+    grids._set_bound(n, solid, grids.BC_NOSLIP, grids.BC_FREE, (0.0, 0.0, 0.0), 1.0)
+    n.type[inner] = grids.NODE_OUT
+    n.bc_vel[inner] = grids.BC_NOSLIP
+    n.bc_temp[inner] = grids.BC_NOSLIP
+    n.T[inner] = 0.0
+    return n, solid
+
+
+@pytest.mark.parametrize("big", [False, True])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_dead_lines_inside_the_fluid(built, kernel, dtype, big):
+    """Whole lines without a solved or merged cell ride along on the pipe kernel's fast paths (kernels_pipe.hip,
+    `dead`): nothing computed for them may reach memory, their temp values must move on unchanged, and whatever
+    their recurrences produce (here also from 1e8-sized values inside the bars) must stay in their lanes."""
+    O = _oracle()
+    g, solid = _bars_grid()
+    s, o = make_pair(g, dtype, kernel, 1)
+    base = [np.ascontiguousarray(a, dtype) for a in (g.vx, g.vy, g.vz, g.T)]
+    cur = grids.perturb(base, seed=21)
+    tmp = grids.perturb(base, seed=22)
+    if big:
+        rng = np.random.default_rng(5)
+        for a in cur + tmp:
+            a[solid] = (rng.standard_normal(int(solid.sum())) * 1e8).astype(dtype)
+    s.upload_layer(capi.LAYER_CUR, cur); s.upload_layer(capi.LAYER_TEMP, tmp)
+    for v in range(4):
+        o.set_field(O.L_CUR, v, cur[v]); o.set_field(O.L_TEMP, v, tmp[v])
+    for d in (capi.DIR_Z, capi.DIR_Y, capi.DIR_X):
+        s.sweep(d, DT, capi.LAYER_CUR, capi.LAYER_TEMP, capi.LAYER_NEXT, merge=True)
+        o.sweep(d, DT, O.L_CUR, O.L_TEMP, O.L_NEXT); o.merge(O.L_NEXT, O.L_TEMP)
+        assert_layers_equal(s, o, capi.LAYER_NEXT, O.L_NEXT, "next after sweep %d" % d)
+        assert_layers_equal(s, o, capi.LAYER_TEMP, O.L_TEMP, "temp after sweep %d" % d)
+    if not big:
+        for step in range(2):
+            s.UpdateBoundaries(); o.update_boundaries()
+            e = s.TimeStep(DT, 2, 2, True)
+            rc, eo = o.time_step(DT, 2, 2, True)
+            assert rc == 0 and e == pytest.approx(eo, rel=1e-12)
+            assert_layers_equal(s, o, capi.LAYER_CUR, O.L_CUR, "cur after step %d" % step)
+            assert_layers_equal(s, o, capi.LAYER_TEMP, O.L_TEMP, "temp after step %d" % step)
