@@ -842,6 +842,9 @@ __global__ void __launch_bounds__(NW * 64, 2) k_sweep_pipe(SweepParams<R> p, int
             p.carry_out[2 * cpitch + cline] = d0;  p.carry_out[3 * cpitch + cline] = d1;
             p.carry_out[4 * cpitch + cline] = d2;  p.carry_out[5 * cpitch + cline] = myD[tl * 64];
         }
+        // handled (the forward half ends here): without this the flag of a bundle that once asked for the full
+        // divisions stayed up and every later forward half was computed twice
+        if (!FM && redo && threadIdx.x == 0) redo[blockIdx.x] = 0;
         return;
     }
     if (MODE == 2) {
