@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libfs3d_hip.so")
-SOURCES = ["fs3d_hip.hip", "fs3d_comm.hip", "kernels_line.hip", "kernels_pipe.hip"]
+SOURCES = ["fs3d_hip.hip", "fs3d_comm.hip", "kernels_line.hip", "kernels_pipe.hip", "kernels_part.hip"]
 HEADERS = ["fs3d_common.h", "fs3d_rows.h", "fs3d_comm.h", os.path.join("..", "..", "include", "fs3d.h")]
 
 # -ffp-contract=off: no FMA contraction, the reference's CPU path rounds after every operation.
@@ -18,6 +18,8 @@ HEADERS = ["fs3d_common.h", "fs3d_rows.h", "fs3d_comm.h", os.path.join("..", "..
 # no -ffast-math, denormals preserved (hipcc default).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value"]
+# kernels_part.hip (partition solve, tolerance-based parity): FMA contraction allowed; everything else as above.
+FLAGS_BY_SOURCE = {"kernels_part.hip": [f for f in FLAGS if f != "-ffp-contract=off"] + ["-ffp-contract=fast"]}
 
 
 def _stale(target, deps):
@@ -36,7 +38,7 @@ def build(force=False, verbose=False):
         obj = os.path.join(CSRC, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+            cmd = [hipcc] + FLAGS_BY_SOURCE.get(s, FLAGS) + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)

@@ -17,7 +17,8 @@ F32, F64 = 0, 1
 OK, ERR_INVALID, ERR_HIP, ERR_DIVERGED, ERR_UNSUPPORTED, ERR_COMM = range(6)
 DIR_X, DIR_Y, DIR_Z = 0, 1, 2
 LAYER_CUR, LAYER_TEMP, LAYER_HALF, LAYER_NEXT = 0, 1, 2, 3
-SWEEP_AUTO, SWEEP_LINE, SWEEP_PIPE = 0, 1, 2
+SWEEP_AUTO, SWEEP_LINE, SWEEP_PIPE, SWEEP_PART, SWEEP_EXACT = 0, 1, 2, 3, 4
+KERNEL_NAMES = {0: "none", 1: "line", 2: "pipe", 3: "part"}
 OPT_SWEEP_KERNEL, OPT_FUSE_MERGE, OPT_DIV_CORE = 0, 1, 2
 
 # every symbol include/fs3d.h declares: name -> (restype, argtypes)
@@ -49,6 +50,7 @@ SYMBOLS = {
     "fs3d_last_step_timing": (_i, [_vp, C.POINTER(C.c_float), C.POINTER(_i)]),
     "fs3d_enable_timing": (_i, [_vp, _i]),
     "fs3d_profile_sweep": (_i, [_vp, _i, _d, _i, _i, _i, C.POINTER(C.c_ulonglong), _i, C.POINTER(_i)]),
+    "fs3d_last_sweep_kernel": (_i, [_vp, _i, C.POINTER(_i), C.POINTER(_i)]),
     "fs3d_version": (C.c_char_p, []),
 }
 
@@ -190,6 +192,15 @@ class Solver:
         self._chk(self.lib.fs3d_profile_sweep(self.h, d, dt, l_cur, l_temp, l_next,
                                               buf.ctypes.data_as(C.POINTER(C.c_ulonglong)), max_blocks, C.byref(nb)))
         return buf[:nb.value]
+
+    def last_sweep_kernels(self):
+        """{"X": "part", "Y": "part", "Z": "pipe"}: what the last sweep of each direction really ran."""
+        out = {}
+        for d, nm in enumerate("XYZ"):
+            k, sg = C.c_int(0), C.c_int(0)
+            self._chk(self.lib.fs3d_last_sweep_kernel(self.h, d, C.byref(k), C.byref(sg)))
+            out[nm] = KERNEL_NAMES.get(k.value, str(k.value)) + ("-segmented" if sg.value else "")
+        return out
 
     def enable_timing(self, on=True):
         self._chk(self.lib.fs3d_enable_timing(self.h, int(on)))

@@ -93,6 +93,8 @@ struct fs3d_ctx {
     hipStream_t stream = nullptr;
     // options
     int opt_kernel = FS3D_SWEEP_AUTO;
+    int ran_kernel[3] = {0, 0, 0};   // per direction: the kernel the last sweep really ran (fs3d_last_sweep_kernel)
+    int ran_segmented[3] = {0, 0, 0};
     int opt_fuse = 1;
     // timing
     bool timing = false;
@@ -120,6 +122,8 @@ struct fs3d_ctx {
 // kernels_*.hip
 template <typename R> void launch_sweep_line(fs3d_ctx *c, int dir, const SweepParams<R> &p);
 template <typename R> bool launch_sweep_pipe(fs3d_ctx *c, int dir, const SweepParams<R> &p); // false: dims unsupported
+// kernels_part.hip: partition (reduced-interface) solve, results to a stated tolerance; false: dims / precision unsupported
+template <typename R> bool launch_sweep_part(fs3d_ctx *c, int dir, const SweepParams<R> &p);
 // X sweep halves of an x-slab for the bundles [b0, b1) (64 lines each, line = j*dimz + k); false: dims unsupported
 template <typename R> bool xslab_pipe_supported(const SweepParams<R> &p);
 template <typename R> bool launch_xslab_pipe(fs3d_ctx *c, SweepParams<R> p, int half, int b0, int b1);

@@ -261,7 +261,7 @@ extern "C" fs3d_status fs3d_set_option(fs3d_ctx *c, int option, int value)
     if (!c) return FS3D_ERR_INVALID;
     switch (option) {
     case FS3D_OPT_SWEEP_KERNEL:
-        if (value < FS3D_SWEEP_AUTO || value > FS3D_SWEEP_PIPE) return fail(c, FS3D_ERR_INVALID, "bad sweep kernel id");
+        if (value < FS3D_SWEEP_AUTO || value > FS3D_SWEEP_EXACT) return fail(c, FS3D_ERR_INVALID, "bad sweep kernel id");
         c->opt_kernel = value; return FS3D_OK;
     case FS3D_OPT_FUSE_MERGE: c->opt_fuse = value ? 1 : 0; return FS3D_OK;
     case FS3D_OPT_DIV_CORE: c->opt_div_core = value ? 1 : 0; return FS3D_OK;
@@ -530,6 +530,7 @@ static fs3d_status xsweep_multi(fs3d_ctx *c, SweepParams<R> &p)
     const int nb = c->xblocks < 1 ? 1 : c->xblocks;
     // per-slab halves: the pipe kernel (rows on chip, 64 lines per bundle) where the slab allows it, else thread-per-line
     const bool pipe = c->opt_kernel != FS3D_SWEEP_LINE && xslab_pipe_supported<R>(p);
+    c->ran_kernel[0] = pipe ? FS3D_SWEEP_PIPE : FS3D_SWEEP_LINE; c->ran_segmented[0] = 1;
     if (c->opt_kernel == FS3D_SWEEP_PIPE && !pipe) return fail(c, FS3D_ERR_UNSUPPORTED, "pipe kernel: slab dims unsupported for the X sweep");
     auto range = [&](int b, long long &l0, long long &l1) {
         const long long per = ((long long)pl / 64 + nb - 1) / nb * 64;      // whole waves / bundles per block
@@ -571,20 +572,30 @@ static fs3d_status sweep_buffers(fs3d_ctx *c, int dir, double dt, int b_cur, int
         return FS3D_OK;
     }
     bool done = false;
-    if (c->opt_kernel != FS3D_SWEEP_LINE) done = launch_sweep_pipe<R>(c, dir, p);
-    if (!done && c->opt_kernel != FS3D_SWEEP_LINE) {
+    const int ok = c->opt_kernel;
+    c->ran_segmented[dir] = 0;
+    if (ok == FS3D_SWEEP_AUTO || ok == FS3D_SWEEP_PART) {
+        done = launch_sweep_part<R>(c, dir, p);
+        if (done) c->ran_kernel[dir] = FS3D_SWEEP_PART;
+        else if (ok == FS3D_SWEEP_PART) { rec_end(c); return fail(c, FS3D_ERR_UNSUPPORTED, "partition sweep kernel does not support these dims / this precision"); }
+    }
+    const bool exact_fast = ok == FS3D_SWEEP_AUTO || ok == FS3D_SWEEP_EXACT || ok == FS3D_SWEEP_PIPE;
+    if (!done && exact_fast) { done = launch_sweep_pipe<R>(c, dir, p); if (done) c->ran_kernel[dir] = FS3D_SWEEP_PIPE; }
+    if (!done && exact_fast) {
         // lines longer than one launch holds on chip: segment by segment, rows through the HBM scratch
         fs3d_status st = ensure_scratch(c);
         if (st) return st;
         p.scr_ = (R *)c->scr;
         done = launch_sweep_pipe_segmented<R>(c, dir, p);
+        if (done) { c->ran_kernel[dir] = FS3D_SWEEP_PIPE; c->ran_segmented[dir] = 1; }
     }
     if (!done) {
-        if (c->opt_kernel == FS3D_SWEEP_PIPE) { rec_end(c); return fail(c, FS3D_ERR_UNSUPPORTED, "pipelined sweep kernel does not support these dims (" + c->err + ")"); }
+        if (ok == FS3D_SWEEP_PIPE) { rec_end(c); return fail(c, FS3D_ERR_UNSUPPORTED, "pipelined sweep kernel does not support these dims (" + c->err + ")"); }
         fs3d_status st = ensure_scratch(c);
         if (st) return st;
         fill_params<R>(c, p, dir, dt, b_cur, b_temp, b_next, b_tout, merge);
         launch_sweep_line<R>(c, dir, p);
+        c->ran_kernel[dir] = FS3D_SWEEP_LINE;
     }
     rec_end(c);
     HIPCHK(c, hipGetLastError());
@@ -601,7 +612,7 @@ extern "C" fs3d_status fs3d_profile_sweep(fs3d_ctx *c, int dir, double dt, int l
     if (!c->have_nodes || !c->have_params) return fail(c, FS3D_ERR_INVALID, "fs3d_profile_sweep: upload nodes and set params first");
     HIPCHK(c, hipSetDevice(c->device));
     const int la = dir == 2 ? c->dimy : c->dimz, n_o = dir == 0 ? c->dimy : c->dimx;
-    const int nb = n_o * ((la + 63) / 64);
+    const int nb = n_o * ((la + 31) / 32);      // enough for the partition kernel's 32-line workgroups too
     if (c->stamps_cap < nb) {
         if (c->stamps) hipFree(c->stamps);
         HIPCHK(c, hipMalloc((void **)&c->stamps, sizeof(unsigned long long) * 64 * (size_t)nb));
@@ -611,7 +622,9 @@ extern "C" fs3d_status fs3d_profile_sweep(fs3d_ctx *c, int dir, double dt, int l
     bool ok;
     if (c->prec == FS3D_F32) {
         SweepParams<float> p; fill_params<float>(c, p, dir, dt, c->slot[l_cur], c->slot[l_temp], c->slot[l_next], c->spare, 1);
-        p.stamps = c->stamps; ok = launch_sweep_pipe<float>(c, dir, p);
+        p.stamps = c->stamps;
+        ok = (c->opt_kernel == FS3D_SWEEP_AUTO || c->opt_kernel == FS3D_SWEEP_PART) && launch_sweep_part<float>(c, dir, p);
+        if (!ok) ok = launch_sweep_pipe<float>(c, dir, p);
     } else {
         SweepParams<double> p; fill_params<double>(c, p, dir, dt, c->slot[l_cur], c->slot[l_temp], c->slot[l_next], c->spare, 1);
         p.stamps = c->stamps; ok = launch_sweep_pipe<double>(c, dir, p);
@@ -847,6 +860,14 @@ extern "C" fs3d_status fs3d_time_step_async(fs3d_ctx *c, double dt, int G, int L
     st = c->prec == FS3D_F32 ? time_step_enqueue<float>(c, dt, G, L, false) : time_step_enqueue<double>(c, dt, G, L, false);
     if (st) return st;
     std::swap(c->slot[FS3D_LAYER_CUR], c->slot[FS3D_LAYER_NEXT]);
+    return FS3D_OK;
+}
+
+extern "C" fs3d_status fs3d_last_sweep_kernel(fs3d_ctx *c, int dir, int *kernel_out, int *segmented_out)
+{
+    if (!c || dir < 0 || dir > 2 || !kernel_out) return FS3D_ERR_INVALID;
+    *kernel_out = c->ran_kernel[dir];
+    if (segmented_out) *segmented_out = c->ran_segmented[dir];
     return FS3D_OK;
 }
 

@@ -1,0 +1,486 @@
+// Partition (reduced-interface) sweep kernels (FS3D_SWEEP_PART) for CDNA4 -- the production path for fp32.
+//
+// What the reference does: one sequential Thomas recurrence per grid line (Common/Algorithms.h:21-38), rows from
+// BuildMatrix / ApplyBC0/1 (FluidSolver3D/AdiSolver3D.cpp:732-852), scatter + merge (UpdateSegment :707-730,
+// MergeFieldTo TimeLayer3D.h:415-436).  The exact kernel (kernels_pipe.hip) keeps that recurrence and therefore
+// a 256-deep serial chain between the loads and the stores of a bundle; it is the bit-exact checker.  Here the
+// line is cut into chunks that are eliminated AT THE SAME TIME, coupled by one small interface system per line
+// (algebra and notation: cmc_fluid_solver_amd/partition.py, tests/test_partition_algebra.py).  Same equations,
+// algebraically exact, different rounding: results agree with the CPU oracle to the tolerance stated in DESIGN.md
+// section 5 (fp32: ~1e-7 rel-L2 per sweep), not bit for bit.  Compiled with FMA contraction; reciprocals are
+// v_rcp_f32 + one Newton step; x/(2h) is a multiplication by the rounded reciprocal.
+//
+// X / Y sweeps  (k_sweep_part): lanes run along k (unit stride).  Workgroup = 32 neighbouring lines x the whole
+//   line; thread (kk, ch) owns the M cells [ch*M, ch*M+M) of line kk, so a wave-wide access is two 128-byte rows.
+//     P   rows of the thread's cells: q = Vs/(2h), dU, dV, dW in registers, dT in LDS (cell-by-cell software
+//         pipeline: the next cells' 12 loads are in flight while a cell is computed)
+//     E   down- and up-sweep over the chunk (independent chains, interleaved) -> interface coefficients to LDS
+//     R   the NCH x NCH interface systems: one thread per (line, right-hand side), 128 threads
+//     S   forward elimination with the left interface value known, back-substitution from the own one
+//     O   scatter x to `next`, merged temp to `temp_out`
+//   6 words per cell stay on chip between P and O: 4 in registers, dT/d'_T and c'_T in registers after P (LDS
+//   during P), nothing goes through HBM.  Two workgroups per CU (<= 128 VGPRs, 68 KiB LDS): one streams while the
+//   other solves.
+// Z sweep  (k_sweep_part_z): lanes run along the line itself: lane l owns cells [4l, 4l+4) of ONE line (a 16-byte
+//   piece; a wave-wide access is the whole contiguous line), neighbouring lines are further registers of the same
+//   lane.  Chunks of a line = lanes of a wave: the interface system is solved by parallel cyclic reduction across
+//   the lanes (shuffles), no LDS, no barrier, nothing resident but the lines in flight.
+#include <algorithm>
+#include <atomic>
+#include <cstdlib>
+#include <type_traits>
+#include <utility>
+#include "fs3d_common.h"
+
+template <typename F, int... I>
+__device__ __forceinline__ void pstatic_for_impl(F &&f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void pstatic_for(F &&f) { pstatic_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+typedef __amdgpu_buffer_rsrc_t prsrc_t;
+typedef unsigned pu32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned pu32x4 __attribute__((ext_vector_type(4)));
+#define PART_OOB 0xFFFFFFFFu      // voffset >= num_records: the hardware drops the store / returns 0 for the load
+
+template <typename R> struct PBuf;
+template <> struct PBuf<float> {
+    static __device__ __forceinline__ float ld(prsrc_t r, unsigned vo, unsigned so) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, vo, so, 0)); }
+    static __device__ __forceinline__ void st(prsrc_t r, unsigned vo, unsigned so, float v) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, vo, so, 0); }
+};
+template <> struct PBuf<double> {
+    static __device__ __forceinline__ double ld(prsrc_t r, unsigned vo, unsigned so) { return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, vo, so, 0)); }
+    static __device__ __forceinline__ void st(prsrc_t r, unsigned vo, unsigned so, double v) { __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(pu32x2, v), r, vo, so, 0); }
+};
+
+// reciprocal: v_rcp_f32 (1 ulp) + one Newton step
+__device__ __forceinline__ float prcp(float y)
+{
+    const float r = __builtin_amdgcn_rcpf(y);
+    return __builtin_fmaf(__builtin_fmaf(-y, r, 1.0f), r, r);
+}
+__device__ __forceinline__ double prcp(double y) { return 1.0 / y; }
+__device__ __forceinline__ float pfma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double pfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+// Opaque copies: the compiler must not merge the (cheap) address / coefficient computations of different phases
+// into one computation whose results stay live -- in scratch memory -- from the first phase to the last.
+template <typename T> __device__ __forceinline__ T opq_v(T x) { asm volatile("" : "+v"(x)); return x; }
+__device__ __forceinline__ unsigned opq_s(unsigned x) { asm volatile("" : "+s"(x)); return x; }
+
+template <typename R> struct PMat { R a, b, c; };
+
+// (a, b, c) of the velocity and the temperature matrix for one cell: INTERIOR rows from q (BuildMatrix,
+// AdiSolver3D.cpp:760-762), the other kinds from the 4-bit row code (ApplyBC0/1, :804-852; SKIP = identity row).
+template <typename R, bool GEN>
+__device__ __forceinline__ void part_coefs(R q, int code4, R vis_v, R b_v, R vis_t, R b_t, PMat<R> &mv, PMat<R> &mt)
+{
+    mv.a = -q - vis_v; mv.b = b_v; mv.c = q - vis_v;
+    mt.a = -q - vis_t; mt.b = b_t; mt.c = q - vis_t;
+    if (GEN) {
+        const int kind = code4 & 3;
+        const bool is_int = kind == ROW_INTERIOR;
+        const bool fv = (code4 & ROW_VELFREE) != 0, ft = (code4 & ROW_TEMPFREE) != 0;
+        mv.a = is_int ? mv.a : ((kind == ROW_END && fv) ? R(-1) : R(0));
+        mv.c = is_int ? mv.c : ((kind == ROW_START && fv) ? R(-1) : R(0));
+        mv.b = is_int ? mv.b : (fv ? R(2) : R(1));
+        mt.a = is_int ? mt.a : ((kind == ROW_END && ft) ? R(-1) : R(0));
+        mt.c = is_int ? mt.c : ((kind == ROW_START && ft) ? R(-1) : R(0));
+        mt.b = is_int ? mt.b : (ft ? R(2) : R(1));
+    }
+}
+
+// one elimination step of a sweep over the chunk: (lead, diag, trail) = (a, b, c) going down, (c, b, a) going up.
+//   den = diag - lead*cp;  rhs' = (rhs - lead*rhs'_prev)/den;  spike' = -lead*spike_prev/den;  cp' = trail/den
+template <typename R, int NR>
+__device__ __forceinline__ void part_step(R lead, R diag, R trail, R &cp, R &sp, R (&dp)[NR], const R (&d)[NR])
+{
+    const R r = prcp(pfma(-lead, cp, diag));
+#pragma unroll
+    for (int k = 0; k < NR; k++) dp[k] = pfma(-lead, dp[k], d[k]) * r;
+    sp = (-lead * sp) * r;
+    cp = trail * r;
+    // pin: the step is evaluated HERE (otherwise the chain is sunk below the per-cell row-kind branches that follow
+    // and every cell's coefficients wait for it in scratch memory)
+    asm volatile("" : "+v"(cp), "+v"(sp));
+#pragma unroll
+    for (int k = 0; k < NR; k++) asm volatile("" : "+v"(dp[k]));
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// X / Y sweeps
+// ------------------------------------------------------------------------------------------------------------
+#ifndef FS3D_PART_PF
+#define FS3D_PART_PF 2            // cells whose loads are in flight ahead of the cell being computed (P phase)
+#endif
+#define PART_EXW 18               // interface words per (line, chunk): 5 per matrix, 2 per right-hand side
+
+template <typename R, int DIR, int M, int NCH, int WPS, int LT, int PF = FS3D_PART_PF>
+__global__ void __launch_bounds__(LT * NCH, WPS) k_sweep_part(SweepParams<R> p, int n_o, int n_tiles, int order)
+{
+    static_assert(DIR == 0 || DIR == 1, "lanes along k: X and Y sweeps");
+    extern __shared__ __attribute__((aligned(16))) unsigned char part_smem[];
+    static_assert(LT == 32 || LT == 64, "lines per workgroup");
+    R *const ldsD = (R *)part_smem;                      // [NCH*M][LT]  dT of every cell (P -> E)
+    R *const ex = ldsD + NCH * M * LT;                  // [PART_EXW][NCH][LT]
+    const int t = threadIdx.x, kk = t % LT, ch = t / LT;
+    // measurement only (fs3d_profile_sweep): 8 s_memtime stamps per wave
+    unsigned long long *const stamp = p.stamps ? p.stamps + ((size_t)blockIdx.x * 8 + (t >> 6) % 8) * 8 : nullptr;
+#define PSTAMP(k) do { if (stamp && (t & 63) == 0 && (t >> 6) < 8) stamp[k] = __builtin_amdgcn_s_memtime(); } while (0)
+    PSTAMP(0);
+
+    // XCD-aware block order (speed only): blocks b, b+8, .. share an XCD under round-robin dispatch; give each XCD a
+    // contiguous range of logical ids so that the o+-1 rows a workgroup reads are streamed by CUs of the same L2
+    int lb = blockIdx.x;
+    {
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, x = lb & 7, slot = lb >> 3;
+        lb = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + slot;
+    }
+    // order 0: consecutive ids = consecutive rows/planes `o` of one lane tile; 1: = the lane tiles of one row/plane
+    // (concurrently running workgroups then stream whole rows: DRAM page locality)
+    const int tile_id = order ? lb % n_tiles : lb / n_o, o = order ? lb / n_tiles : lb - tile_id * n_o;
+
+    const int n = DIR == 0 ? p.dimx : p.dimy;
+    const int la_len = p.dimz;
+    const int k = tile_id * LT + kk;
+    const bool lane_valid = k < la_len;
+    const int kc = lane_valid ? k : la_len - 1;
+    const long long ss = DIR == 0 ? p.plane : (long long)p.dimz;     // element stride along the sweep
+    const long long os = DIR == 0 ? (long long)p.dimz : p.plane;     // element stride of the `o` axis
+    const int s0 = ch * M;
+    const unsigned ssb_p = (unsigned)(ss * (long long)sizeof(R)), osb = (unsigned)(os * (long long)sizeof(R));
+    const unsigned fsb_p = (unsigned)(p.fstride * (long long)sizeof(R)), nsb = (unsigned)(p.nstride * (long long)sizeof(R));
+    const unsigned ssb = ssb_p, fsb = fsb_p;
+    // per-lane element offset of the chunk's first cell; the wave-uniform rest goes through the scalar offset
+    const unsigned vel = (unsigned)((long long)s0 * ss + kc);
+    const unsigned vo = vel * (unsigned)sizeof(R);
+    const unsigned so0_p = (unsigned)((p.plane + (long long)o * os) * (long long)sizeof(R));  // layer fields: one halo plane first
+    const unsigned so0 = so0_p;
+    const unsigned son = (unsigned)(((long long)o * os) * (long long)sizeof(R));              // node values / codes: no halo plane
+    const unsigned lbytes = 4u * fsb;
+    const prsrc_t Lcur = __builtin_amdgcn_make_buffer_rsrc((void *)(p.cur_ - p.plane), 0, (int)lbytes, 0x00020000);
+    const prsrc_t Ltmp = __builtin_amdgcn_make_buffer_rsrc((void *)(p.temp_ - p.plane), 0, (int)lbytes, 0x00020000);
+    const prsrc_t Lnext = __builtin_amdgcn_make_buffer_rsrc((void *)(p.next_ - p.plane), 0, (int)lbytes, 0x00020000);
+    const prsrc_t Ltout = __builtin_amdgcn_make_buffer_rsrc((void *)(p.temp_out_ - p.plane), 0, (int)lbytes, 0x00020000);
+    const prsrc_t rNode = __builtin_amdgcn_make_buffer_rsrc((void *)p.node_, 0, (int)(4u * nsb), 0x00020000);
+    const prsrc_t rCode = __builtin_amdgcn_make_buffer_rsrc((void *)p.code, 0, (int)(nsb / (sizeof(R) / 2)), 0x00020000);
+
+    const R ir2s = R(1) / p.two_ds[DIR];
+    constexpr int M1 = DIR == 0 ? 1 : 0;                 // axis of the `o` neighbours
+    constexpr int M2 = 2;                                // lane axis
+    const R ir2o = R(1) / p.two_ds[M1], ir2l = R(1) / p.two_ds[M2];
+    const R k3dt = R(3) / p.dt;
+    const R vis_v = p.vis_v, vis_t = p.vis_t, b_v = p.b_v, b_t = p.b_t;
+
+    // ---- row codes of the chunk: 4 bits per cell, NODE_IN mask, INTERIOR mask --------------------------------
+    constexpr int NCP = (M + 7) / 8;
+    unsigned cpack[NCP];
+    unsigned inmask = 0, intmask = 0, segmask = 0;
+    {
+        int cwv[M];
+        unsigned s_c = (son / (unsigned)sizeof(R)) * 2u;
+        const unsigned ssc = (ssb / (unsigned)sizeof(R)) * 2u;
+#pragma unroll
+        for (int i = 0; i < M; i++) { cwv[i] = __builtin_amdgcn_raw_buffer_load_b16(rCode, vel * 2u, s_c, 0); s_c = opq_s(s_c + ssc); }
+#pragma unroll
+        for (int i = 0; i < NCP; i++) cpack[i] = 0;
+#pragma unroll
+        for (int i = 0; i < M; i++) {
+            int cw = cwv[i] & 0xFFFF;
+            cw = (s0 + i < n) ? cw : 0;                  // cells past the end of the line: SKIP rows, never stored
+            const int code4 = (cw >> (4 * DIR)) & 0xF;
+            cpack[i >> 3] |= (unsigned)code4 << (4 * (i & 7));
+            if (((cw >> CODE_TYPE_SHIFT) & 3) == FS3D_NODE_IN && s0 + i < n) inmask |= 1u << i;
+            if ((code4 & 3) == ROW_INTERIOR) intmask |= 1u << i;
+            if ((code4 & 3) != ROW_SKIP) segmask |= 1u << i;
+        }
+        // pin: the packed forms are computed here (otherwise their computation is sunk to the O phase and the M raw
+        // code words wait for it in scratch memory)
+        asm volatile("" : "+v"(inmask), "+v"(segmask), "+v"(intmask));
+#pragma unroll
+        for (int i = 0; i < NCP; i++) asm volatile("" : "+v"(cpack[i]));
+    }
+    // cells that are INTERIOR rows on all 64 lanes of the wave: plain scalar branches pick the select-free code
+    unsigned umask;
+    {
+        unsigned m = intmask;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) m &= (unsigned)__shfl_xor((int)m, d, 64);
+        umask = (unsigned)__builtin_amdgcn_readfirstlane((int)m);
+    }
+    // opaque per use: the lane masks derived from a code (SGPR pairs) must not be shared between the phases
+    auto code_of = [&](int i) __attribute__((always_inline)) { return (int)((opq_v(cpack[i >> 3]) >> (4 * (i & 7))) & 0xFu); };
+
+    PSTAMP(1);
+    // ---- P: rows -------------------------------------------------------------------------------------------
+    R q[M], dU[M], dV[M], dW[M];
+    {
+        struct CellLd { R tp[4], c[4], om, op, lm, lp; };
+        // running scalar offsets, opaque from cell to cell: otherwise the offsets of all M cells are computed up front and
+        // held in (spilled) SGPRs
+        unsigned s_is = so0, s_nd = son;
+        auto issue = [&](CellLd &L) __attribute__((always_inline)) {
+            const unsigned sc = s_is;
+            s_is = opq_s(s_is + ssb);
+#pragma unroll
+            for (int f = 0; f < 4; f++) L.tp[f] = PBuf<R>::ld(Ltmp, vo, sc + ssb + (unsigned)f * fsb);
+#pragma unroll
+            for (int f = 0; f < 4; f++) L.c[f] = PBuf<R>::ld(Lcur, vo, sc + (unsigned)f * fsb);
+            const unsigned sv = sc + (unsigned)DIR * fsb;
+            L.om = PBuf<R>::ld(Ltmp, vo, sv - osb); L.op = PBuf<R>::ld(Ltmp, vo, sv + osb);
+            L.lm = PBuf<R>::ld(Ltmp, vo, sv - (unsigned)sizeof(R)); L.lp = PBuf<R>::ld(Ltmp, vo, sv + (unsigned)sizeof(R));
+        };
+        R Tm[4], Tc[4];
+#pragma unroll
+        for (int f = 0; f < 4; f++) { Tm[f] = PBuf<R>::ld(Ltmp, vo, so0 - ssb + (unsigned)f * fsb); Tc[f] = PBuf<R>::ld(Ltmp, vo, so0 + (unsigned)f * fsb); }
+        CellLd L[PF + 1];
+#pragma unroll
+        for (int i = 0; i < PF && i < M; i++) issue(L[i]);
+        pstatic_for<M>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            if (i + PF < M) issue(L[(i + PF) % (PF + 1)]);
+            __builtin_amdgcn_sched_barrier(0);
+            const CellLd &c = L[i % (PF + 1)];
+            R qq = Tc[DIR] * ir2s;
+            R g[4];
+#pragma unroll
+            for (int f = 0; f < 4; f++) g[f] = (c.tp[f] - Tm[f]) * ir2s;          // d/ds of U, V, W, T (TimeLayer3D.h:338-340)
+            const R x1 = (c.op - c.om) * ir2o, x2 = (c.lp - c.lm) * ir2l;          // d(Vs)/d(o axis), d(Vs)/d(lane axis)
+            const R t0 = (DIR == 0 ? R(2) : R(1)) * g[0] * g[0], t1 = (DIR == 1 ? R(2) : R(1)) * g[1] * g[1], t2 = g[2] * g[2];
+            const R diss = (((t0 + t1) + t2) + g[M1] * x1) + g[M2] * x2;          // DissFuncX/Y (TimeLayer3D.h:554-577)
+            R dd[4];
+#pragma unroll
+            for (int f = 0; f < 3; f++) dd[f] = c.c[f] * k3dt;
+            dd[DIR] = pfma(-p.v_T, g[3], dd[DIR]);
+            dd[3] = pfma(c.c[3], k3dt, p.t_phi * diss);
+            if (!((opq_s(umask) >> i) & 1u)) {
+                // some line has another row kind here: START/END  d = node value (NOSLIP) or 0 (FREE); SKIP  d = 0
+                const int code4 = code_of(i), kind = code4 & 3;
+                const bool is_int = kind == ROW_INTERIOR;
+                const bool ns_v = kind != ROW_SKIP && !(code4 & ROW_VELFREE), ns_t = kind != ROW_SKIP && !(code4 & ROW_TEMPFREE);
+                R nv[4];
+#pragma unroll
+                for (int f = 0; f < 4; f++) nv[f] = PBuf<R>::ld(rNode, vo, s_nd + (unsigned)f * nsb);
+                qq = is_int ? qq : R(0);
+#pragma unroll
+                for (int f = 0; f < 3; f++) dd[f] = is_int ? dd[f] : (ns_v ? nv[f] : R(0));
+                dd[3] = is_int ? dd[3] : (ns_t ? nv[3] : R(0));
+            }
+            q[i] = qq; dU[i] = dd[0]; dV[i] = dd[1]; dW[i] = dd[2];
+            ldsD[(s0 + i) * LT + kk] = dd[3];
+#pragma unroll
+            for (int f = 0; f < 4; f++) { Tm[f] = Tc[f]; Tc[f] = c.tp[f]; }
+            s_nd = opq_s(s_nd + ssb);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    }
+
+    PSTAMP(2);
+    // ---- E: chunk elimination -> interface coefficients ------------------------------------------------------
+    // every use recomputes the coefficients from an opaque copy of q (4 operations) instead of keeping 6 x M values alive
+    auto coefs = [&](int i, PMat<R> &mv, PMat<R> &mt) __attribute__((always_inline)) {
+        const R qi = opq_v(q[i]);
+        if ((opq_s(umask) >> i) & 1u) part_coefs<R, false>(qi, 0, vis_v, b_v, vis_t, b_t, mv, mt);
+        else part_coefs<R, true>(qi, code_of(i), vis_v, b_v, vis_t, b_t, mv, mt);
+    };
+    const R *const myD = ldsD + (s0 * LT + kk);         // dT of local cell i at myD[i * LT] (this thread wrote it: no barrier)
+    {
+        R cpv = R(0), lpv = R(-1), cpt = R(0), lpt = R(-1), dp3[3] = {R(0), R(0), R(0)}, dp1[1] = {R(0)};   // down: x[M-2] = dp - lp X_{p-1} - cp X_p
+        R apv = R(0), upv = R(-1), apt = R(0), upt = R(-1), ep3[3] = {R(0), R(0), R(0)}, ep1[1] = {R(0)};   // up:   x[0]   = ep - ap X_{p-1} - up X_p
+        // the T right-hand sides stay in the LDS during this phase (register budget); read one step ahead of their use
+        R tdn = myD[0], tup = myD[(M - 2) * LT];
+        pstatic_for<M - 1>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value, j = M - 2 - i;
+            const R tdi = tdn, tdj = tup;
+            if (i + 1 < M - 1) { tdn = myD[(i + 1) * LT]; tup = myD[(j - 1 < 0 ? 0 : j - 1) * LT]; }
+            PMat<R> mv, mt, nv, nt;
+            coefs(i, mv, mt);
+            coefs(j, nv, nt);
+            { const R d3[3] = {dU[i], dV[i], dW[i]}; part_step<R, 3>(mv.a, mv.b, mv.c, cpv, lpv, dp3, d3); }
+            { const R d1[1] = {tdi}; part_step<R, 1>(mt.a, mt.b, mt.c, cpt, lpt, dp1, d1); }
+            { const R d3[3] = {dU[j], dV[j], dW[j]}; part_step<R, 3>(nv.c, nv.b, nv.a, apv, upv, ep3, d3); }
+            { const R d1[1] = {tdj}; part_step<R, 1>(nt.c, nt.b, nt.a, apt, upt, ep1, d1); }
+        });
+        // the interface cell's own row with x[M-2] eliminated:  A X_{p-1} + Bp X_p + cl x_first(p+1) = Dp
+        PMat<R> lv, lt;
+        coefs(M - 1, lv, lt);
+        R *const e = ex + (ch * LT + kk);
+        constexpr int ES = NCH * LT;
+        e[0 * ES] = -lv.a * lpv; e[1 * ES] = pfma(-lv.a, cpv, lv.b); e[2 * ES] = lv.c; e[3 * ES] = apv; e[4 * ES] = upv;
+        e[5 * ES] = -lt.a * lpt; e[6 * ES] = pfma(-lt.a, cpt, lt.b); e[7 * ES] = lt.c; e[8 * ES] = apt; e[9 * ES] = upt;
+        e[10 * ES] = pfma(-lv.a, dp3[0], dU[M - 1]); e[11 * ES] = pfma(-lv.a, dp3[1], dV[M - 1]);
+        e[12 * ES] = pfma(-lv.a, dp3[2], dW[M - 1]); e[13 * ES] = pfma(-lt.a, dp1[0], myD[(M - 1) * LT]);
+        e[14 * ES] = ep3[0]; e[15 * ES] = ep3[1]; e[16 * ES] = ep3[2]; e[17 * ES] = ep1[0];
+    }
+    PSTAMP(3);
+    __syncthreads();
+    PSTAMP(4);
+
+    // ---- R: interface systems, one thread per (line, right-hand side) ----------------------------------------
+    if (t < 4 * LT) {
+        constexpr int ES = NCH * LT;
+        const int sys = t / LT;
+        const R *const em = ex + (sys == 3 ? 5 * ES : 0) + kk;      // this system's matrix words
+        R *const er = ex + (10 + sys) * ES + kk;                    // Dp (-> X), Gf at + 4*ES
+        R cpa[NCH], dpa[NCH];
+        R cp = R(0), dp = R(0);
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            const R lo = em[0 * ES + c * LT], bp = em[1 * ES + c * LT], cl = em[2 * ES + c * LT];
+            R vf = R(0), wf = R(0), gf = R(0);
+            if (c + 1 < NCH) { vf = em[3 * ES + (c + 1) * LT]; wf = em[4 * ES + (c + 1) * LT]; gf = er[4 * ES + (c + 1) * LT]; }
+            const R di = pfma(-cl, vf, bp), up = -cl * wf, rhs = pfma(-cl, gf, er[c * LT]);
+            const R r = prcp(pfma(-lo, cp, di));
+            cp = up * r; dp = pfma(-lo, dp, rhs) * r;
+            cpa[c] = cp; dpa[c] = dp;
+        }
+        R x = dpa[NCH - 1];
+        er[(NCH - 1) * LT] = x;
+#pragma unroll
+        for (int c = NCH - 2; c >= 0; c--) { x = pfma(-cpa[c], x, dpa[c]); er[c * LT] = x; }
+    }
+    __syncthreads();
+    PSTAMP(5);
+
+    // ---- S: the chunk with both interface values known ---------------------------------------------------------
+    R cT[M], dT[M];                                     // c'_T and d'_T, then x_T in dT
+    {
+        constexpr int ES = NCH * LT;
+        R xo[4], dp3[3], dp1[1];
+#pragma unroll
+        for (int s = 0; s < 4; s++) xo[s] = ex[(10 + s) * ES + ch * LT + kk];
+#pragma unroll
+        for (int s = 0; s < 3; s++) dp3[s] = ch > 0 ? ex[(10 + s) * ES + (ch - 1) * LT + kk] : R(0);
+        dp1[0] = ch > 0 ? ex[13 * ES + (ch - 1) * LT + kk] : R(0);
+        R cpv = R(0), cpt = R(0), sp = R(0);
+        R tdn = myD[0];
+        pstatic_for<M - 1>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            const R tdi = tdn;
+            if (i + 1 < M - 1) tdn = myD[(i + 1) * LT];
+            PMat<R> mv, mt;
+            coefs(i, mv, mt);
+            { const R d3[3] = {dU[i], dV[i], dW[i]}; part_step<R, 3>(mv.a, mv.b, mv.c, cpv, sp, dp3, d3); }
+            { const R d1[1] = {tdi}; part_step<R, 1>(mt.a, mt.b, mt.c, cpt, sp, dp1, d1); }
+            q[i] = cpv; cT[i] = cpt; dU[i] = dp3[0]; dV[i] = dp3[1]; dW[i] = dp3[2]; dT[i] = dp1[0];
+        });
+        dU[M - 1] = xo[0]; dV[M - 1] = xo[1]; dW[M - 1] = xo[2]; dT[M - 1] = xo[3];
+#pragma unroll
+        for (int i = M - 2; i >= 0; i--) {
+            xo[0] = pfma(-q[i], xo[0], dU[i]); xo[1] = pfma(-q[i], xo[1], dV[i]);
+            xo[2] = pfma(-q[i], xo[2], dW[i]); xo[3] = pfma(-cT[i], xo[3], dT[i]);
+            dU[i] = xo[0]; dV[i] = xo[1]; dW[i] = xo[2]; dT[i] = xo[3];
+        }
+    }
+
+    PSTAMP(6);
+    // ---- O: scatter + merge -------------------------------------------------------------------------------------
+    {
+        const unsigned vo_st = lane_valid ? vo : PART_OOB;
+        const unsigned so0 = opq_s(so0_p), ssb = opq_s(ssb_p), fsb = opq_s(fsb_p);   // not the P phase's address arithmetic kept alive
+        constexpr int OPF = 2;                          // cells whose temp values are in flight ahead
+        R tv[OPF + 1][4];
+        unsigned s_is = so0, s_o = so0;                 // running scalar offsets (issue side / store side), opaque per cell
+        const unsigned segm = opq_v(segmask), inm = opq_v(inmask);
+        const int nloc = opq_v(n - s0);                 // cells of this chunk inside the line
+        auto issue = [&](R (&v)[4]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int f = 0; f < 4; f++) v[f] = PBuf<R>::ld(Ltmp, vo, s_is + (unsigned)f * fsb);
+            s_is = opq_s(s_is + ssb);
+        };
+        if (p.merge) {
+#pragma unroll
+            for (int i = 0; i < OPF && i < M; i++) issue(tv[i]);
+        }
+        pstatic_for<M>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            const unsigned sc = s_o;
+            s_o = opq_s(s_o + ssb);
+            if (p.merge && i + OPF < M) issue(tv[(i + OPF) % (OPF + 1)]);
+            __builtin_amdgcn_sched_barrier(0);
+            R xv[4] = {dU[i], dV[i], dW[i], dT[i]};
+            const bool uni = (opq_s(umask) >> i) & 1u;
+            const bool seg = uni || ((segm >> i) & 1u), isin = uni || ((inm >> i) & 1u);
+            const bool in_line = i < nloc;
+            if (p.store_next) {
+                const unsigned v_ = seg ? vo_st : PART_OOB;            // UpdateSegment: every cell of a segment, nothing else
+#pragma unroll
+                for (int f = 0; f < 4; f++) PBuf<R>::st(Lnext, v_, sc + (unsigned)f * fsb, xv[f]);
+            }
+            if (p.merge) {
+                R (&tq)[4] = tv[i % (OPF + 1)];
+                if (!uni && __any(isin && !seg)) {
+                    // NODE_IN cell outside every segment (run without a closing cell, Grid3D.cpp:87-117): the reference
+                    // merges the stale `next` value
+#pragma unroll
+                    for (int f = 0; f < 4; f++) { const R sv = PBuf<R>::ld(Lnext, vo, sc + (unsigned)f * fsb); xv[f] = (isin && !seg) ? sv : xv[f]; }
+                }
+                const unsigned v_ = in_line ? vo_st : PART_OOB;
+#pragma unroll
+                for (int f = 0; f < 4; f++) {
+                    R mv = (tq[f] + xv[f]) * R(0.5);                                   // MergeFieldTo (TimeLayer3D.h:415-436)
+                    if (p.merge == 2) mv = (mv + xv[f]) * R(0.5);
+                    PBuf<R>::st(Ltout, v_, sc + (unsigned)f * fsb, isin ? mv : tq[f]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    }
+    PSTAMP(7);
+#undef PSTAMP
+}
+
+template <typename R, int DIR, int M, int NCH, int WPS, int LT, int PF = FS3D_PART_PF>
+static bool part_launch_xy(fs3d_ctx *c, const SweepParams<R> &p)
+{
+    const int n_o = DIR == 0 ? p.dimy : p.dimx;
+    const int n_tiles = (p.dimz + LT - 1) / LT;
+    const size_t lds = ((size_t)NCH * M * LT + (size_t)PART_EXW * NCH * LT) * sizeof(R);
+    static std::atomic<unsigned long long> attr_set{0};
+    const unsigned long long dev_bit = 1ull << (c->device & 63);
+    if (!(attr_set.load() & dev_bit)) {
+        if (hipFuncSetAttribute((const void *)k_sweep_part<R, DIR, M, NCH, WPS, LT, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            c->err = std::string("partition kernel: hipFuncSetAttribute: ") + hipGetErrorString(hipGetLastError());
+            return false;
+        }
+        attr_set.fetch_or(dev_bit);
+    }
+    static const int order = getenv("FS3D_PART_ORDER") ? atoi(getenv("FS3D_PART_ORDER")) : 0;   // kernel experiments
+    hipLaunchKernelGGL((k_sweep_part<R, DIR, M, NCH, WPS, LT, PF>), dim3((unsigned)(n_o * n_tiles)), dim3(LT * NCH), lds, c->stream, p, n_o, n_tiles, order);
+    return true;
+}
+
+template <typename R, int DIR>
+static bool part_dispatch_xy(fs3d_ctx *c, const SweepParams<R> &p)
+{
+    const int n = DIR == 0 ? p.dimx : p.dimy;
+    if (n < 4) return false;
+    if (std::is_same<R, float>::value) {
+        static const int variant = getenv("FS3D_PART_VARIANT") ? atoi(getenv("FS3D_PART_VARIANT")) : 0;   // kernel experiments
+        if (n <= 64) return part_launch_xy<R, DIR, 16, 4, 4, 32>(c, p);
+        if (n <= 128) return part_launch_xy<R, DIR, 16, 8, 4, 32>(c, p);
+        if (n <= 256) {
+            if (variant == 1) return part_launch_xy<R, DIR, 32, 8, 2, 32>(c, p);     // 256 threads x 32 cells, <= 256 VGPRs
+            if (variant == 2) return part_launch_xy<R, DIR, 16, 16, 4, 64>(c, p);    // 64 lines: one workgroup per CU
+            if (variant == 3) return part_launch_xy<R, DIR, 32, 8, 2, 64>(c, p);     // 64 lines x 32 cells, 512 threads, one per CU
+            if (variant == 4) return part_launch_xy<R, DIR, 16, 16, 4, 32, 1>(c, p);
+            if (variant == 5) return part_launch_xy<R, DIR, 16, 16, 4, 32, 3>(c, p);
+            if (variant == 6) return part_launch_xy<R, DIR, 32, 8, 2, 32, 4>(c, p);
+            return part_launch_xy<R, DIR, 16, 16, 4, 32>(c, p);
+        }
+        if (n <= 512) return part_launch_xy<R, DIR, 16, 32, 4, 32>(c, p);
+    }
+    return false;
+}
+
+// false: dims / precision / slab configuration not covered -> the caller falls back to the exact kernels
+template <typename R>
+bool launch_sweep_part(fs3d_ctx *c, int dir, const SweepParams<R> &p)
+{
+    if ((unsigned long long)p.fstride * 4ull * sizeof(R) >= (1ull << 32)) return false;   // 32-bit buffer offsets span a layer
+    if (dir == 0 && (p.ghost_lo || p.ghost_hi)) return false;                            // X sweep of an x-slab: own path
+    if (dir == 0) return part_dispatch_xy<R, 0>(c, p);
+    if (dir == 1) return part_dispatch_xy<R, 1>(c, p);
+    return false;
+}
+template bool launch_sweep_part<float>(fs3d_ctx *, int, const SweepParams<float> &);
+template bool launch_sweep_part<double>(fs3d_ctx *, int, const SweepParams<double> &);

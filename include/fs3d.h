@@ -51,9 +51,13 @@ enum { FS3D_VAR_U = 0, FS3D_VAR_V = 1, FS3D_VAR_W = 2, FS3D_VAR_T = 3 };
 
 /* kernel selection for the line sweeps (fs3d_set_option(FS3D_OPT_SWEEP_KERNEL)) */
 enum {
-    FS3D_SWEEP_AUTO = 0,      /* fastest kernel that supports the dims */
-    FS3D_SWEEP_LINE = 1,      /* thread-per-line Thomas, c'/d' scratch in HBM (any dims) */
-    FS3D_SWEEP_PIPE = 2       /* wave-pipelined Thomas, c'/d' in registers+LDS */
+    FS3D_SWEEP_AUTO = 0,      /* fastest kernel that supports the dims: PART where it applies (fp32), else as EXACT */
+    FS3D_SWEEP_LINE = 1,      /* thread-per-line Thomas, c'/d' scratch in HBM (any dims); bit-equal to the CPU path */
+    FS3D_SWEEP_PIPE = 2,      /* wave-pipelined Thomas, c'/d' in registers+LDS; bit-equal to the CPU path */
+    FS3D_SWEEP_PART = 3,      /* partition (reduced-interface) solve: every chunk of a line eliminated at once; same
+                                 equations, different rounding -- equal to the CPU path to a stated tolerance
+                                 (DESIGN.md section 5), not bit for bit; errors where it does not apply */
+    FS3D_SWEEP_EXACT = 4      /* fastest of the bit-exact kernels (PIPE, its segmented form, LINE) */
 };
 enum {
     FS3D_OPT_SWEEP_KERNEL = 0,
@@ -184,6 +188,11 @@ fs3d_status fs3d_enable_timing(fs3d_ctx *ctx, int on);
  * stamps_out holds max_blocks*64 values.  Measurement aid; no reference counterpart. */
 fs3d_status fs3d_profile_sweep(fs3d_ctx *ctx, int dir, double dt, int l_cur, int l_temp, int l_next,
                                unsigned long long *stamps_out, int max_blocks, int *n_blocks_out);
+
+/* Which kernel the last sweep of direction dir (FS3D_DIR_*) really ran: FS3D_SWEEP_LINE / _PIPE / _PART, with
+ * *segmented_out (optional) = 1 when PIPE ran as segment halves through the HBM scratch.  0 = no sweep yet.
+ * FS3D_SWEEP_AUTO never falls back silently: callers (bench.py, fs3d_run) print this. */
+fs3d_status fs3d_last_sweep_kernel(fs3d_ctx *ctx, int dir, int *kernel_out, int *segmented_out);
 
 /* library / device identification */
 const char *fs3d_version(void);
