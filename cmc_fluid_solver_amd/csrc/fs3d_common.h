@@ -34,6 +34,7 @@ struct SweepParams {
     R *temp_out_;               // merged temp (== temp_ when not double-buffered)
     long long fstride;          // elements between consecutive fields of a layer
     const uint16_t *code;
+    const uint8_t *dead;        // per line of the sweep direction: 1 = no cell of the line is on a segment or NODE_IN (partition kernels)
     const R *node_;             // node boundary values (v.x, v.y, v.z, T), field v at + v*nstride
     R *scr_;                    // LINE kernel scratch: c'_uvw, c'_T, d'_U, d'_V, d'_W, d'_T at + v*nstride
     long long nstride;          // = number of owned cells
@@ -77,6 +78,7 @@ struct fs3d_ctx {
     int slot[4] = {0, 1, 2, 3}; // layer id -> buffer
     int spare = 4;
     uint16_t *code = nullptr;
+    uint8_t *dead[3] = {};      // per direction, one byte per line: the line has no segment cell and no NODE_IN cell (X: [j][k], Y: [i][k], Z: [i][j])
     void *node = nullptr;       // 4 x ncell
     void *scr = nullptr;        // >= 6 x ncell: rows of the thread-per-line kernel / of the pipe kernel's halves (allocated on demand)
     size_t scr_bytes = 0;

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "fs3d_common.h"
@@ -208,6 +209,10 @@ extern "C" fs3d_status fs3d_create(fs3d_ctx **out, int device, fs3d_precision pr
     c->gdx = dx; c->gdy = dy; c->gdz = dz;
     c->esize = prec == FS3D_F32 ? 4 : 8;
     c->plane = (long long)dimy * dimz; c->ncell = c->plane * dimx;
+    if (const char *e = getenv("FS3D_DEFAULT_KERNEL")) {       // initial FS3D_OPT_SWEEP_KERNEL of new contexts (tests: 4 = bit-exact kernels only)
+        const int v = atoi(e);
+        if (v >= FS3D_SWEEP_AUTO && v <= FS3D_SWEEP_EXACT) c->opt_kernel = v;
+    }
 #define CK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { char b_[256]; snprintf(b_, sizeof b_, "GPU %d: %s failed: %s", device, #call, hipGetErrorString(e_)); g_create_err = b_; fs3d_destroy(c); return FS3D_ERR_HIP; } } while (0)
     CK(hipSetDevice(device));
     CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -237,6 +242,7 @@ extern "C" void fs3d_destroy(fs3d_ctx *c)
     if (c->redo) hipFree(c->redo);
     for (int i = 0; i < 2; i++) if (c->seg_carry[i]) hipFree(c->seg_carry[i]);
     if (c->code) hipFree(c->code);
+    for (int d = 0; d < 3; d++) if (c->dead[d]) hipFree(c->dead[d]);
     if (c->node) hipFree(c->node);
     if (c->scr) hipFree(c->scr);
     for (int v = 0; v < 4; v++) if (c->bnd_val[v]) hipFree(c->bnd_val[v]);
@@ -378,6 +384,22 @@ static fs3d_status upload_nodes_impl(fs3d_ctx *c, const uint8_t *type, const uin
     }
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpy(c->code, code.data(), code.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    {
+        // dead lines: no cell of the (local part of the) line is on a segment of that direction or NODE_IN -- nothing a
+        // sweep computes for such a line is ever stored; the partition kernels keep them off the row-kind paths
+        const long long nl[3] = {(long long)dy * dz, (long long)nx * dz, (long long)nx * dy};
+        for (int d = 0; d < 3; d++) {
+            std::vector<uint8_t> dead((size_t)nl[d], 1);
+            for (long long l = 0; l < c->ncell; l++) {
+                const int i = (int)(l / plane), rem = (int)(l - (long long)i * plane), j = rem / dz, k = rem - j * dz;
+                const bool live = ((code[(size_t)l] >> (4 * d)) & 3) != ROW_SKIP || ((code[(size_t)l] >> CODE_TYPE_SHIFT) & 3) == FS3D_NODE_IN;
+                if (live) dead[(size_t)(d == 0 ? (long long)j * dz + k : (d == 1 ? (long long)i * dz + k : (long long)i * dy + j))] = 0;
+            }
+            if (c->dead[d]) { hipFree(c->dead[d]); c->dead[d] = nullptr; }
+            HIPCHK(c, hipMalloc((void **)&c->dead[d], (size_t)nl[d]));
+            HIPCHK(c, hipMemcpy(c->dead[d], dead.data(), (size_t)nl[d], hipMemcpyHostToDevice));
+        }
+    }
     for (int v = 0; v < 4; v++)
         HIPCHK(c, hipMemcpy((R *)c->node + (size_t)v * c->ncell, nv[v].data(), (size_t)c->ncell * sizeof(R), hipMemcpyHostToDevice));
     if (c->bnd_idx) { hipFree(c->bnd_idx); c->bnd_idx = nullptr; }
@@ -481,6 +503,7 @@ static void fill_params(fs3d_ctx *c, SweepParams<R> &p, int dir, double dt_, int
     p.fstride = c->fstride;
     p.node_ = (const R *)c->node; p.scr_ = (R *)c->scr; p.nstride = c->ncell;
     p.code = c->code;
+    p.dead = c->dead[dir];
     // every constant below is evaluated in FTYPE exactly as the reference writes it
     const R dx = (R)c->gdx, dy = (R)c->gdy, dz = (R)c->gdz;          // TimeLayer3D.h:1078-1080
     const R ds = dir == 0 ? dx : (dir == 1 ? dy : dz);

@@ -62,6 +62,13 @@ __device__ __forceinline__ double prcp(double y) { return 1.0 / y; }
 __device__ __forceinline__ float pfma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double pfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
+// x / y for a divisor y that is constant over the kernel (2h, dt), r = 1/y rounded: one correction step on x*r.
+// The plain product x*r would carry the rounding error of r into EVERY cell with the same sign -- a systematic
+// perturbation of the advection coefficients and right-hand sides (like a slightly different h or dt) that does not
+// average out over the steps; with the correction the quotient is the correctly rounded one in all but rare cases.
+__device__ __forceinline__ float pdivc(float x, float y, float r) { const float q = x * r; return __builtin_fmaf(__builtin_fmaf(-y, q, x), r, q); }
+__device__ __forceinline__ double pdivc(double x, double y, double) { return x / y; }
+
 // Opaque copies: the compiler must not merge the (cheap) address / coefficient computations of different phases
 // into one computation whose results stay live -- in scratch memory -- from the first phase to the last.
 template <typename T> __device__ __forceinline__ T opq_v(T x) { asm volatile("" : "+v"(x)); return x; }
@@ -91,14 +98,27 @@ __device__ __forceinline__ void part_coefs(R q, int code4, R vis_v, R b_v, R vis
 
 // one elimination step of a sweep over the chunk: (lead, diag, trail) = (a, b, c) going down, (c, b, a) going up.
 //   den = diag - lead*cp;  rhs' = (rhs - lead*rhs'_prev)/den;  spike' = -lead*spike_prev/den;  cp' = trail/den
+// Measured on the shipped 64^3 example against the fp64 oracle: with the correction the partition kernels deviate
+// from the fp64 solution as much as the sequential fp32 recurrence does (8.5e-7 vs 7.9e-7 after 10 steps, 1.2e-6 vs
+// 1.0e-6 after 30); without it twice as much.  No measurable cost: the phases that divide are not the ones that bind.
+#ifndef FS3D_PART_QCORR
+#define FS3D_PART_QCORR 1         // 1: every quotient of the elimination gets a correction step (correctly rounded x/den)
+#endif
+template <typename R>
+__device__ __forceinline__ R pquot(R num, R den, R r)
+{
+    const R q = num * r;
+    return FS3D_PART_QCORR ? pfma(pfma(-den, q, num), r, q) : q;
+}
 template <typename R, int NR>
 __device__ __forceinline__ void part_step(R lead, R diag, R trail, R &cp, R &sp, R (&dp)[NR], const R (&d)[NR])
 {
-    const R r = prcp(pfma(-lead, cp, diag));
+    const R den = pfma(-lead, cp, diag);
+    const R r = prcp(den);
 #pragma unroll
-    for (int k = 0; k < NR; k++) dp[k] = pfma(-lead, dp[k], d[k]) * r;
-    sp = (-lead * sp) * r;
-    cp = trail * r;
+    for (int k = 0; k < NR; k++) dp[k] = pquot(pfma(-lead, dp[k], d[k]), den, r);
+    sp = pquot(-lead * sp, den, r);
+    cp = pquot(trail, den, r);
     // pin: the step is evaluated HERE (otherwise the chain is sunk below the per-cell row-kind branches that follow
     // and every cell's coefficients wait for it in scratch memory)
     asm volatile("" : "+v"(cp), "+v"(sp));
@@ -137,7 +157,8 @@ __global__ void __launch_bounds__(LT * NCH, WPS) k_sweep_part(SweepParams<R> p, 
     }
     // order 0: consecutive ids = consecutive rows/planes `o` of one lane tile; 1: = the lane tiles of one row/plane
     // (concurrently running workgroups then stream whole rows: DRAM page locality)
-    const int tile_id = order ? lb % n_tiles : lb / n_o, o = order ? lb / n_tiles : lb - tile_id * n_o;
+    const bool x_nonb = order & 2, x_nore = order & 4;      // timing experiments only (wrong numbers): FS3D_PART_ORDER bits 1, 2
+    const int tile_id = (order & 1) ? lb % n_tiles : lb / n_o, o = (order & 1) ? lb / n_tiles : lb - tile_id * n_o;
 
     const int n = DIR == 0 ? p.dimx : p.dimy;
     const int la_len = p.dimz;
@@ -164,11 +185,10 @@ __global__ void __launch_bounds__(LT * NCH, WPS) k_sweep_part(SweepParams<R> p, 
     const prsrc_t rNode = __builtin_amdgcn_make_buffer_rsrc((void *)p.node_, 0, (int)(4u * nsb), 0x00020000);
     const prsrc_t rCode = __builtin_amdgcn_make_buffer_rsrc((void *)p.code, 0, (int)(nsb / (sizeof(R) / 2)), 0x00020000);
 
-    const R ir2s = R(1) / p.two_ds[DIR];
     constexpr int M1 = DIR == 0 ? 1 : 0;                 // axis of the `o` neighbours
     constexpr int M2 = 2;                                // lane axis
-    const R ir2o = R(1) / p.two_ds[M1], ir2l = R(1) / p.two_ds[M2];
-    const R k3dt = R(3) / p.dt;
+    const R h2s = p.two_ds[DIR], h2o = p.two_ds[M1], h2l = p.two_ds[M2], dtv = p.dt;
+    const R ir2s = R(1) / h2s, ir2o = R(1) / h2o, ir2l = R(1) / h2l, irdt = R(1) / dtv;
     const R vis_v = p.vis_v, vis_t = p.vis_t, b_v = p.b_v, b_t = p.b_t;
 
     // ---- row codes of the chunk: 4 bits per cell, NODE_IN mask, INTERIOR mask --------------------------------
@@ -199,10 +219,14 @@ __global__ void __launch_bounds__(LT * NCH, WPS) k_sweep_part(SweepParams<R> p, 
 #pragma unroll
         for (int i = 0; i < NCP; i++) asm volatile("" : "+v"(cpack[i]));
     }
+    // Dead lines (the wall lines of a box): nothing computed for them is stored, temp_out receives their old temp.
+    // They must not keep the other lines of the wave off the select-free paths: they run along as INTERIOR rows --
+    // finite or not, whatever they produce stays in its lane (and in its own interface system).
+    const bool dead = p.dead[(long long)o * p.dimz + kc] != 0;
     // cells that are INTERIOR rows on all 64 lanes of the wave: plain scalar branches pick the select-free code
     unsigned umask;
     {
-        unsigned m = intmask;
+        unsigned m = dead ? 0xFFFFFFFFu : intmask;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) m &= (unsigned)__shfl_xor((int)m, d, 64);
         umask = (unsigned)__builtin_amdgcn_readfirstlane((int)m);
@@ -226,8 +250,11 @@ __global__ void __launch_bounds__(LT * NCH, WPS) k_sweep_part(SweepParams<R> p, 
 #pragma unroll
             for (int f = 0; f < 4; f++) L.c[f] = PBuf<R>::ld(Lcur, vo, sc + (unsigned)f * fsb);
             const unsigned sv = sc + (unsigned)DIR * fsb;
-            L.om = PBuf<R>::ld(Ltmp, vo, sv - osb); L.op = PBuf<R>::ld(Ltmp, vo, sv + osb);
-            L.lm = PBuf<R>::ld(Ltmp, vo, sv - (unsigned)sizeof(R)); L.lp = PBuf<R>::ld(Ltmp, vo, sv + (unsigned)sizeof(R));
+            if (x_nonb) { L.om = L.op = L.lm = L.lp = L.c[0]; }
+            else {
+                L.om = PBuf<R>::ld(Ltmp, vo, sv - osb); L.op = PBuf<R>::ld(Ltmp, vo, sv + osb);
+                L.lm = PBuf<R>::ld(Ltmp, vo, sv - (unsigned)sizeof(R)); L.lp = PBuf<R>::ld(Ltmp, vo, sv + (unsigned)sizeof(R));
+            }
         };
         R Tm[4], Tc[4];
 #pragma unroll
@@ -240,18 +267,18 @@ __global__ void __launch_bounds__(LT * NCH, WPS) k_sweep_part(SweepParams<R> p, 
             if (i + PF < M) issue(L[(i + PF) % (PF + 1)]);
             __builtin_amdgcn_sched_barrier(0);
             const CellLd &c = L[i % (PF + 1)];
-            R qq = Tc[DIR] * ir2s;
+            R qq = pdivc(Tc[DIR], h2s, ir2s);
             R g[4];
 #pragma unroll
-            for (int f = 0; f < 4; f++) g[f] = (c.tp[f] - Tm[f]) * ir2s;          // d/ds of U, V, W, T (TimeLayer3D.h:338-340)
-            const R x1 = (c.op - c.om) * ir2o, x2 = (c.lp - c.lm) * ir2l;          // d(Vs)/d(o axis), d(Vs)/d(lane axis)
+            for (int f = 0; f < 4; f++) g[f] = pdivc(c.tp[f] - Tm[f], h2s, ir2s);          // d/ds of U, V, W, T (TimeLayer3D.h:338-340)
+            const R x1 = pdivc(c.op - c.om, h2o, ir2o), x2 = pdivc(c.lp - c.lm, h2l, ir2l);   // d(Vs)/d(o axis), d(Vs)/d(lane axis)
             const R t0 = (DIR == 0 ? R(2) : R(1)) * g[0] * g[0], t1 = (DIR == 1 ? R(2) : R(1)) * g[1] * g[1], t2 = g[2] * g[2];
             const R diss = (((t0 + t1) + t2) + g[M1] * x1) + g[M2] * x2;          // DissFuncX/Y (TimeLayer3D.h:554-577)
             R dd[4];
 #pragma unroll
-            for (int f = 0; f < 3; f++) dd[f] = c.c[f] * k3dt;
+            for (int f = 0; f < 3; f++) dd[f] = pdivc(c.c[f] * R(3), dtv, irdt);    // cur * 3 / dt (AdiSolver3D.cpp:764-799)
             dd[DIR] = pfma(-p.v_T, g[3], dd[DIR]);
-            dd[3] = pfma(c.c[3], k3dt, p.t_phi * diss);
+            dd[3] = pfma(p.t_phi, diss, pdivc(c.c[3] * R(3), dtv, irdt));
             if (!((opq_s(umask) >> i) & 1u)) {
                 // some line has another row kind here: START/END  d = node value (NOSLIP) or 0 (FREE); SKIP  d = 0
                 const int code4 = code_of(i), kind = code4 & 3;
@@ -329,8 +356,8 @@ __global__ void __launch_bounds__(LT * NCH, WPS) k_sweep_part(SweepParams<R> p, 
             R vf = R(0), wf = R(0), gf = R(0);
             if (c + 1 < NCH) { vf = em[3 * ES + (c + 1) * LT]; wf = em[4 * ES + (c + 1) * LT]; gf = er[4 * ES + (c + 1) * LT]; }
             const R di = pfma(-cl, vf, bp), up = -cl * wf, rhs = pfma(-cl, gf, er[c * LT]);
-            const R r = prcp(pfma(-lo, cp, di));
-            cp = up * r; dp = pfma(-lo, dp, rhs) * r;
+            const R den = pfma(-lo, cp, di), r = prcp(den);
+            cp = pquot(up, den, r); dp = pquot(pfma(-lo, dp, rhs), den, r);
             cpa[c] = cp; dpa[c] = dp;
         }
         R x = dpa[NCH - 1];
@@ -384,7 +411,7 @@ __global__ void __launch_bounds__(LT * NCH, WPS) k_sweep_part(SweepParams<R> p, 
         const int nloc = opq_v(n - s0);                 // cells of this chunk inside the line
         auto issue = [&](R (&v)[4]) __attribute__((always_inline)) {
 #pragma unroll
-            for (int f = 0; f < 4; f++) v[f] = PBuf<R>::ld(Ltmp, vo, s_is + (unsigned)f * fsb);
+            for (int f = 0; f < 4; f++) v[f] = x_nore ? R(f) : PBuf<R>::ld(Ltmp, vo, s_is + (unsigned)f * fsb);
             s_is = opq_s(s_is + ssb);
         };
         if (p.merge) {
@@ -399,7 +426,7 @@ __global__ void __launch_bounds__(LT * NCH, WPS) k_sweep_part(SweepParams<R> p, 
             __builtin_amdgcn_sched_barrier(0);
             R xv[4] = {dU[i], dV[i], dW[i], dT[i]};
             const bool uni = (opq_s(umask) >> i) & 1u;
-            const bool seg = uni || ((segm >> i) & 1u), isin = uni || ((inm >> i) & 1u);
+            const bool seg = !dead && (uni || ((segm >> i) & 1u)), isin = !dead && (uni || ((inm >> i) & 1u));
             const bool in_line = i < nloc;
             if (p.store_next) {
                 const unsigned v_ = seg ? vo_st : PART_OOB;            // UpdateSegment: every cell of a segment, nothing else
@@ -460,17 +487,366 @@ static bool part_dispatch_xy(fs3d_ctx *c, const SweepParams<R> &p)
         if (n <= 128) return part_launch_xy<R, DIR, 16, 8, 4, 32>(c, p);
         if (n <= 256) {
             if (variant == 1) return part_launch_xy<R, DIR, 32, 8, 2, 32>(c, p);     // 256 threads x 32 cells, <= 256 VGPRs
-            if (variant == 2) return part_launch_xy<R, DIR, 16, 16, 4, 64>(c, p);    // 64 lines: one workgroup per CU
             if (variant == 3) return part_launch_xy<R, DIR, 32, 8, 2, 64>(c, p);     // 64 lines x 32 cells, 512 threads, one per CU
             if (variant == 4) return part_launch_xy<R, DIR, 16, 16, 4, 32, 1>(c, p);
             if (variant == 5) return part_launch_xy<R, DIR, 16, 16, 4, 32, 3>(c, p);
             if (variant == 6) return part_launch_xy<R, DIR, 32, 8, 2, 32, 4>(c, p);
-            return part_launch_xy<R, DIR, 16, 16, 4, 32>(c, p);
+            if (variant == 7) return part_launch_xy<R, DIR, 16, 16, 4, 32>(c, p);    // 32 lines, two workgroups per CU
+            // 64 lines x 16 chunks: 256-byte row pieces (measured: 1.1x the speed of 128-byte pieces in the Y sweep, 1.2x in X)
+            return part_launch_xy<R, DIR, 16, 16, 4, 64>(c, p);
         }
         if (n <= 512) return part_launch_xy<R, DIR, 16, 32, 4, 32>(c, p);
     }
     return false;
 }
+
+
+// ------------------------------------------------------------------------------------------------------------
+// Z sweep: lanes along the line
+// ------------------------------------------------------------------------------------------------------------
+// Lane l of a line owns the 4 cells [4l, 4l+4): one 16-byte piece, so a wave-wide access is LI = 64/LPL whole
+// contiguous lines (LPL lanes per line: 64 for 128 < dimz <= 256).  A wave works through LG such rows of lines, one
+// after the other, with the next row's loads in flight; nothing is shared between waves (no LDS, no barrier).
+// Per line:  rows of the 4 cells -> down-/up-sweep over cells 0..2 -> the interface row of cell 3 -> the LPL x LPL
+// interface system by parallel cyclic reduction across the lanes (log2(LPL) steps of shuffles) -> back-substitution
+// -> x to `next`, merged temp to `temp_out`; the temp values needed by the merge are still in registers.
+typedef float pf4 __attribute__((ext_vector_type(4)));
+struct PV4 { float v[4]; };
+__device__ __forceinline__ PV4 pld4(prsrc_t r, unsigned vo, unsigned so)
+{
+    const pu32x4 q = __builtin_amdgcn_raw_buffer_load_b128(r, vo, so, 0);
+    PV4 o;
+    __builtin_memcpy(o.v, &q, 16);
+    return o;
+}
+__device__ __forceinline__ void pst4(prsrc_t r, unsigned vo, unsigned so, const float (&v)[4])
+{
+    pu32x4 q;
+    __builtin_memcpy(&q, v, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(q, r, vo, so, 0);
+    // A 16-byte store reads its data registers a few cycles after it issues.  hipcc pads a following VALU write of
+    // those registers only for stores without a scalar offset; here (SGPR soffset) it reused them two instructions
+    // later and the first dword of the NEXT field's data reached memory (seen on gfx950: sporadic, last lanes of a
+    // line).  The four values stay live until this statement, which supplies the wait states.
+    asm volatile("s_nop 1" : : "v"(q.x), "v"(q.y), "v"(q.z), "v"(q.w));
+}
+
+struct ZLine { PV4 tc[4], cu[4], wim, wip, wjm, wjp; pu32x2 code; float nve[4]; };   // wjm/wjp: only where a wave-wide access holds several lines
+
+template <int LPL, int WPS>
+__global__ void __launch_bounds__(256, WPS) k_sweep_part_z(SweepParams<float> p, int n_grp, int LG)
+{
+    typedef float R;
+    constexpr int LI = 64 / LPL;                        // lines per wave-wide access
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l = lane % LPL, sub = lane / LPL;
+    int lb = blockIdx.x;
+    {
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, x = lb & 7, slot = lb >> 3;
+        lb = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + slot;
+    }
+    // task = (group of LG*LI lines, plane): consecutive tasks = consecutive planes of one line group
+    const int task = lb * 4 + w;
+    const int grp = task / p.dimx, i = task - grp * p.dimx;
+    if (grp >= n_grp) return;                           // whole wave (wave-uniform)
+    const int n = p.dimz;
+    const int j0 = grp * LG * LI;
+    const bool l_ok = 4 * l < n;
+    const int lc = l_ok ? l : (n / 4 - 1);
+    const unsigned fsb = (unsigned)(p.fstride * 4ll), nsb = (unsigned)(p.nstride * 4ll);
+    const unsigned rowb = (unsigned)p.dimz * 4u, planeb = (unsigned)(p.plane * 4ll);
+    const unsigned lbytes = 4u * fsb;
+    const prsrc_t Lcur = __builtin_amdgcn_make_buffer_rsrc((void *)(p.cur_ - p.plane), 0, (int)lbytes, 0x00020000);
+    const prsrc_t Ltmp = __builtin_amdgcn_make_buffer_rsrc((void *)(p.temp_ - p.plane), 0, (int)lbytes, 0x00020000);
+    const prsrc_t Lnext = __builtin_amdgcn_make_buffer_rsrc((void *)(p.next_ - p.plane), 0, (int)lbytes, 0x00020000);
+    const prsrc_t Ltout = __builtin_amdgcn_make_buffer_rsrc((void *)(p.temp_out_ - p.plane), 0, (int)lbytes, 0x00020000);
+    const prsrc_t rNode = __builtin_amdgcn_make_buffer_rsrc((void *)p.node_, 0, (int)(4u * nsb), 0x00020000);
+    const prsrc_t rCode = __builtin_amdgcn_make_buffer_rsrc((void *)p.code, 0, (int)(nsb / 2u), 0x00020000);
+
+    const R h2s = p.two_ds[2], h2o = p.two_ds[0], h2l = p.two_ds[1], dtv = p.dt;
+    const R ir2s = R(1) / h2s, ir2o = R(1) / h2o, ir2l = R(1) / h2l, irdt = R(1) / dtv;
+    const R vis_v = p.vis_v, vis_t = p.vis_t, b_v = p.b_v, b_t = p.b_t;
+
+    // byte offset of (plane i, line j, cell 0) inside a layer field (one halo plane first) / inside the node arrays
+    auto line_so = [&](int j) __attribute__((always_inline)) { return (unsigned)(((long long)(i + 1) * p.plane + (long long)j * p.dimz) * 4ll); };
+    auto line_son = [&](int j) __attribute__((always_inline)) { return (unsigned)(((long long)i * p.plane + (long long)j * p.dimz) * 4ll); };
+    const unsigned vo_l = (unsigned)(sub * p.dimz + 4 * lc) * 4u;          // per-lane bytes: own line of the row, own piece
+    // the two lanes that hold the ends of the line (cell 0: START or SKIP; cell n-1: END or SKIP) fetch that cell's node
+    // values with the line's other loads: every line has them, they must not cost a memory round trip of their own
+    const bool is_end = l_ok && (l == 0 || l == n / 4 - 1);
+    const int ec = l == 0 ? 0 : 3;
+    const unsigned vo_e = is_end ? vo_l + 4u * (unsigned)ec : PART_OOB;
+
+    auto issue = [&](int jrow, ZLine &L) __attribute__((always_inline)) {
+        // jrow: first line of the row (wave-uniform); this lane's line is jrow + sub, clamped into the plane for the loads
+        const int jr = jrow < p.dimy ? jrow : p.dimy - 1;   // a row past the plane (tail of the last group): valid addresses, nothing stored
+        const unsigned so = opq_s(line_so(jr));
+        L.tc[2] = pld4(Ltmp, vo_l, so + 2u * fsb);       // W first: the row before needs it as its j+1 neighbour... and the stencils
+        L.tc[0] = pld4(Ltmp, vo_l, so); L.tc[1] = pld4(Ltmp, vo_l, so + fsb); L.tc[3] = pld4(Ltmp, vo_l, so + 3u * fsb);
+#pragma unroll
+        for (int f = 0; f < 4; f++) L.cu[f] = pld4(Lcur, vo_l, so + (unsigned)f * fsb);
+        L.wim = pld4(Ltmp, vo_l, so + 2u * fsb - planeb); L.wip = pld4(Ltmp, vo_l, so + 2u * fsb + planeb);
+        if (LI > 1) { L.wjm = pld4(Ltmp, vo_l, so + 2u * fsb - rowb); L.wjp = pld4(Ltmp, vo_l, so + 2u * fsb + rowb); }
+        const unsigned son = opq_s(line_son(jr));
+        L.code = __builtin_amdgcn_raw_buffer_load_b64(rCode, vo_l / 2u, son / 2u, 0);
+#pragma unroll
+        for (int f = 0; f < 4; f++) L.nve[f] = PBuf<R>::ld(rNode, vo_e, son + (unsigned)f * nsb);     // other lanes: out of range, no memory access
+    };
+
+    // wjm / wjp: W of the lines j-1 / j+1 (LI == 1: the neighbouring rows' registers; else loaded with the line)
+    auto process = [&](int jrow, const ZLine &L, const PV4 &wjm, const PV4 &wjp) __attribute__((always_inline)) {
+        const int j = jrow + sub;
+        const bool st_ok = l_ok && j < p.dimy;           // lines past the plane compute on whatever was loaded, nothing is stored
+        const unsigned so = opq_s(line_so(jrow)), son = opq_s(line_son(jrow));
+        // ---- codes
+        int code4[4]; bool isin[4], seg[4], inter[4];
+        bool all_int = true;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            int cw = (int)((c < 2 ? L.code.x : L.code.y) >> (16 * (c & 1))) & 0xFFFF;
+            cw = l_ok ? cw : 0;
+            code4[c] = (cw >> 8) & 0xF;
+            isin[c] = ((cw >> CODE_TYPE_SHIFT) & 3) == FS3D_NODE_IN && l_ok;
+            inter[c] = (code4[c] & 3) == ROW_INTERIOR;
+            seg[c] = (code4[c] & 3) != ROW_SKIP;
+            all_int = all_int && inter[c];
+        }
+        // ---- rows: neighbours along the line from the lanes next door
+        R tm1[4], tp4[4];                                 // cell 4l-1 and cell 4l+4 of U, V, W, T
+#pragma unroll
+        for (int f = 0; f < 4; f++) { tm1[f] = __shfl_up(L.tc[f].v[3], 1, LPL); tp4[f] = __shfl_down(L.tc[f].v[0], 1, LPL); }
+        R q[4], d[4][4];                                  // d[f][c]
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            R g[4];
+#pragma unroll
+            for (int f = 0; f < 4; f++) {
+                const R lo = c == 0 ? tm1[f] : L.tc[f].v[c == 0 ? 0 : c - 1], hi = c == 3 ? tp4[f] : L.tc[f].v[c == 3 ? 3 : c + 1];
+                g[f] = pdivc(hi - lo, h2s, ir2s);         // d/dz of U, V, W, T
+            }
+            const R x1 = pdivc(L.wip.v[c] - L.wim.v[c], h2o, ir2o), x2 = pdivc(wjp.v[c] - wjm.v[c], h2l, ir2l);   // dW/dx, dW/dy
+            const R diss = (((g[0] * g[0] + g[1] * g[1]) + R(2) * g[2] * g[2]) + g[0] * x1) + g[1] * x2;   // DissFuncZ (TimeLayer3D.h:578-588)
+            q[c] = pdivc(L.tc[2].v[c], h2s, ir2s);
+            d[0][c] = pdivc(L.cu[0].v[c] * R(3), dtv, irdt); d[1][c] = pdivc(L.cu[1].v[c] * R(3), dtv, irdt);
+            d[2][c] = pfma(-p.v_T, g[3], pdivc(L.cu[2].v[c] * R(3), dtv, irdt));
+            d[3][c] = pfma(p.t_phi, diss, pdivc(L.cu[3].v[c] * R(3), dtv, irdt));
+        }
+        PMat<R> mv[4], mt[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) part_coefs<R, false>(q[c], 0, vis_v, b_v, vis_t, b_t, mv[c], mt[c]);
+        {
+            // Rows that are not INTERIOR: the ends of every line (node values came with the line) and, rarely, obstacles /
+            // lanes past the line (their node values are fetched here).  Per cell slot c a wave-uniform test: in a box only
+            // c = 0 (first lane) and c = 3 (last lane) take the selects.
+            bool slow = false;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int kind = code4[c] & 3;
+                slow = slow || ((kind == ROW_START || kind == ROW_END) && !(is_end && c == ec));
+            }
+            PV4 nv[4];
+            if (__any(slow)) {
+#pragma unroll
+                for (int f = 0; f < 4; f++) nv[f] = pld4(rNode, vo_l, son + (unsigned)f * nsb);
+            }
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                if (__any(!inter[c])) {
+                    const int kind = code4[c] & 3;
+                    const bool ns_v = kind != ROW_SKIP && !(code4[c] & ROW_VELFREE), ns_t = kind != ROW_SKIP && !(code4[c] & ROW_TEMPFREE);
+                    const bool pre = is_end && c == ec;
+                    part_coefs<R, true>(q[c], code4[c], vis_v, b_v, vis_t, b_t, mv[c], mt[c]);
+#pragma unroll
+                    for (int f = 0; f < 3; f++) d[f][c] = inter[c] ? d[f][c] : (ns_v ? (pre ? L.nve[f] : nv[f].v[c]) : R(0));
+                    d[3][c] = inter[c] ? d[3][c] : (ns_t ? (pre ? L.nve[3] : nv[3].v[c]) : R(0));
+                }
+            }
+        }
+        // ---- chunk elimination: down-sweep over cells 0..2 (kept for the back-substitution), up-sweep 2..0
+        R cpv[3], lpv[3], cpt[3], lpt[3], dpd[3][4];
+        {
+            R cv = R(0), lv = R(-1), ct = R(0), lt = R(-1), d3[3] = {R(0), R(0), R(0)}, d1[1] = {R(0)};
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                { const R dd3[3] = {d[0][c], d[1][c], d[2][c]}; part_step<R, 3>(mv[c].a, mv[c].b, mv[c].c, cv, lv, d3, dd3); }
+                { const R dd1[1] = {d[3][c]}; part_step<R, 1>(mt[c].a, mt[c].b, mt[c].c, ct, lt, d1, dd1); }
+                cpv[c] = cv; lpv[c] = lv; cpt[c] = ct; lpt[c] = lt;
+                dpd[c][0] = d3[0]; dpd[c][1] = d3[1]; dpd[c][2] = d3[2]; dpd[c][3] = d1[0];
+            }
+        }
+        R apv = R(0), upv = R(-1), apt = R(0), upt = R(-1), ep3[3] = {R(0), R(0), R(0)}, ep1[1] = {R(0)};
+#pragma unroll
+        for (int c = 2; c >= 0; c--) {
+            { const R dd3[3] = {d[0][c], d[1][c], d[2][c]}; part_step<R, 3>(mv[c].c, mv[c].b, mv[c].a, apv, upv, ep3, dd3); }
+            { const R dd1[1] = {d[3][c]}; part_step<R, 1>(mt[c].c, mt[c].b, mt[c].a, apt, upt, ep1, dd1); }
+        }
+        // ---- interface row (cell 3) with x[2] eliminated and x_first of the next lane substituted; normalised
+        R av, cv_, at, ct_, dd[4];
+        {
+            const R nvf = __shfl_down(apv, 1, LPL), nwf = __shfl_down(upv, 1, LPL), ntf = __shfl_down(apt, 1, LPL), nuf = __shfl_down(upt, 1, LPL);
+            const R ng0 = __shfl_down(ep3[0], 1, LPL), ng1 = __shfl_down(ep3[1], 1, LPL), ng2 = __shfl_down(ep3[2], 1, LPL), ng3 = __shfl_down(ep1[0], 1, LPL);
+            const bool last = l == LPL - 1;                // no lane behind: its first cell does not exist (the row has c = 0 anyway)
+            const R clv = last ? R(0) : mv[3].c, clt = last ? R(0) : mt[3].c;
+            const R lov = -mv[3].a * lpv[2], div = pfma(-clv, nvf, pfma(-mv[3].a, cpv[2], mv[3].b)), upv_ = -clv * nwf;
+            const R lot = -mt[3].a * lpt[2], dit = pfma(-clt, ntf, pfma(-mt[3].a, cpt[2], mt[3].b)), upt_ = -clt * nuf;
+            const R rv = prcp(div), rt = prcp(dit);
+            av = pquot(lov, div, rv); cv_ = pquot(upv_, div, rv); at = pquot(lot, dit, rt); ct_ = pquot(upt_, dit, rt);
+            dd[0] = pquot(pfma(-clv, ng0, pfma(-mv[3].a, dpd[2][0], d[0][3])), div, rv);
+            dd[1] = pquot(pfma(-clv, ng1, pfma(-mv[3].a, dpd[2][1], d[1][3])), div, rv);
+            dd[2] = pquot(pfma(-clv, ng2, pfma(-mv[3].a, dpd[2][2], d[2][3])), div, rv);
+            dd[3] = pquot(pfma(-clt, ng3, pfma(-mt[3].a, dpd[2][3], d[3][3])), dit, rt);
+        }
+        // ---- parallel cyclic reduction over the LPL lanes of the line
+#pragma unroll
+        for (int s = 1; s < LPL; s <<= 1) {
+            const R amv = __shfl_up(av, s, LPL), cmv = __shfl_up(cv_, s, LPL), apv_ = __shfl_down(av, s, LPL), cpv_ = __shfl_down(cv_, s, LPL);
+            const R amt = __shfl_up(at, s, LPL), cmt = __shfl_up(ct_, s, LPL), apt_ = __shfl_down(at, s, LPL), cpt_ = __shfl_down(ct_, s, LPL);
+            R dm[4], dq[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) { dm[k] = __shfl_up(dd[k], s, LPL); dq[k] = __shfl_down(dd[k], s, LPL); }
+            // lanes without a partner at this distance: their a (c) is zero by now, the partner values must only be finite
+            const bool has_m = l >= s, has_p = l + s < LPL;
+            const R a_v = has_m ? av : R(0), c_v = has_p ? cv_ : R(0), a_t = has_m ? at : R(0), c_t = has_p ? ct_ : R(0);
+            const R dnv = pfma(-a_v, cmv, pfma(-c_v, apv_, R(1))), dnt = pfma(-a_t, cmt, pfma(-c_t, apt_, R(1)));
+            const R rv = prcp(dnv), rt = prcp(dnt);
+#pragma unroll
+            for (int k = 0; k < 3; k++) dd[k] = pquot(pfma(-a_v, dm[k], pfma(-c_v, dq[k], dd[k])), dnv, rv);
+            dd[3] = pquot(pfma(-a_t, dm[3], pfma(-c_t, dq[3], dd[3])), dnt, rt);
+            av = pquot(-a_v * amv, dnv, rv); cv_ = pquot(-c_v * cpv_, dnv, rv);
+            at = pquot(-a_t * amt, dnt, rt); ct_ = pquot(-c_t * cpt_, dnt, rt);
+        }
+        // ---- back-substitution: x[3] = X, x[c] = d'[c] - l[c] X_left - c'[c] x[c+1]
+        R x[4][4];                                        // x[f][c]
+        {
+            R xl[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) { xl[k] = __shfl_up(dd[k], 1, LPL); xl[k] = l == 0 ? R(0) : xl[k]; x[k][3] = dd[k]; }
+#pragma unroll
+            for (int c = 2; c >= 0; c--) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) x[k][c] = pfma(-cpv[c], x[k][c + 1], pfma(-lpv[c], xl[k], dpd[c][k]));
+                x[3][c] = pfma(-cpt[c], x[3][c + 1], pfma(-lpt[c], xl[3], dpd[c][3]));
+            }
+        }
+        // ---- scatter + merge
+        const unsigned vo_st = st_ok ? vo_l : PART_OOB;
+        const bool all_seg = seg[0] && seg[1] && seg[2] && seg[3];
+        if (p.store_next) {
+            if (__all(all_seg || !st_ok)) {
+#pragma unroll
+                for (int f = 0; f < 4; f++) pst4(Lnext, vo_st, so + (unsigned)f * fsb, x[f]);
+            } else {
+#pragma unroll
+                for (int f = 0; f < 4; f++)
+#pragma unroll
+                    for (int c = 0; c < 4; c++)
+                        PBuf<R>::st(Lnext, seg[c] ? vo_st : PART_OOB, so + (unsigned)f * fsb + 4u * (unsigned)c, x[f][c]);
+            }
+        }
+        if (p.merge) {
+            bool stale = false;
+#pragma unroll
+            for (int c = 0; c < 4; c++) stale = stale || (isin[c] && !seg[c]);
+            if (__any(stale)) {
+                // NODE_IN cell outside every segment: the reference merges the stale `next` value (Grid3D.cpp:87-117)
+#pragma unroll
+                for (int f = 0; f < 4; f++) {
+                    const PV4 sv = pld4(Lnext, vo_l, so + (unsigned)f * fsb);
+#pragma unroll
+                    for (int c = 0; c < 4; c++) x[f][c] = (isin[c] && !seg[c]) ? sv.v[c] : x[f][c];
+                }
+            }
+#pragma unroll
+            for (int f = 0; f < 4; f++) {
+                R o4[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    R mvv = (L.tc[f].v[c] + x[f][c]) * R(0.5);       // MergeFieldTo (TimeLayer3D.h:415-436)
+                    if (p.merge == 2) mvv = (mvv + x[f][c]) * R(0.5);
+                    o4[c] = isin[c] ? mvv : L.tc[f].v[c];
+                }
+                pst4(Ltout, vo_st, so + (unsigned)f * fsb, o4);
+            }
+        }
+    };
+
+    // ---- the rows of this wave's group, two per trip, the next row's loads in flight
+    // LI == 1: W of the lines j-1 / j+1 are the previous / next row's registers; the lines just outside the group come
+    // from two extra loads.  (The next row's W is its first load: it has arrived long before the rest.)
+    ZLine La, Lb;
+    PV4 wprev, wedge;
+    if (LI == 1) {
+        wprev = pld4(Ltmp, vo_l, opq_s(line_so(j0)) + 2u * fsb - rowb);
+        const int jl = j0 + LG < p.dimy ? j0 + LG : p.dimy - 1;
+        wedge = pld4(Ltmp, vo_l, opq_s(line_so(jl)) + 2u * fsb);
+    }
+    issue(j0, La);
+    for (int r = 0; r < LG; r += 2) {
+        const int ja = j0 + r * LI, jb = ja + LI, jc = jb + LI;
+        if (r + 1 < LG) issue(jb, Lb);
+        __builtin_amdgcn_sched_barrier(0);
+        if (LI == 1) {
+            PV4 wn;
+#pragma unroll
+            for (int c = 0; c < 4; c++) wn.v[c] = wedge.v[c];
+            if (r + 1 < LG) {
+#pragma unroll
+                for (int c = 0; c < 4; c++) wn.v[c] = Lb.tc[2].v[c];
+            }
+            process(ja, La, wprev, wn);
+#pragma unroll
+            for (int c = 0; c < 4; c++) wprev.v[c] = La.tc[2].v[c];
+        }
+        else process(ja, La, La.wjm, La.wjp);
+        __builtin_amdgcn_sched_barrier(0);
+        if (r + 1 < LG) {
+            if (r + 2 < LG) issue(jc, La);
+            __builtin_amdgcn_sched_barrier(0);
+            if (LI == 1) {
+                PV4 wn;
+#pragma unroll
+                for (int c = 0; c < 4; c++) wn.v[c] = wedge.v[c];
+                if (r + 2 < LG) {
+#pragma unroll
+                    for (int c = 0; c < 4; c++) wn.v[c] = La.tc[2].v[c];
+                }
+                process(jb, Lb, wprev, wn);
+#pragma unroll
+                for (int c = 0; c < 4; c++) wprev.v[c] = Lb.tc[2].v[c];
+            }
+            else process(jb, Lb, Lb.wjm, Lb.wjp);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+template <int LPL>
+static bool part_launch_z(fs3d_ctx *c, const SweepParams<float> &p)
+{
+    constexpr int LI = 64 / LPL;
+    static const int lg_env = getenv("FS3D_PART_ZLG") ? atoi(getenv("FS3D_PART_ZLG")) : 0;     // kernel experiments
+    int LG = lg_env > 0 ? lg_env : 8;
+    const int rows = (p.dimy + LI - 1) / LI;              // rows of LI lines per plane
+    if (LG > rows) LG = rows;
+    const int n_grp = (rows + LG - 1) / LG;
+    const long long tasks = (long long)n_grp * p.dimx;
+    static const int wps = getenv("FS3D_PART_ZWPS") ? atoi(getenv("FS3D_PART_ZWPS")) : 2;     // kernel experiments
+    if (wps == 3) hipLaunchKernelGGL((k_sweep_part_z<LPL, 3>), dim3((unsigned)((tasks + 3) / 4)), dim3(256), 0, c->stream, p, n_grp, LG);
+    else hipLaunchKernelGGL((k_sweep_part_z<LPL, 2>), dim3((unsigned)((tasks + 3) / 4)), dim3(256), 0, c->stream, p, n_grp, LG);
+    return true;
+}
+
+static bool part_dispatch_z(fs3d_ctx *c, const SweepParams<float> &p)
+{
+    const int n = p.dimz;
+    if (n % 4 != 0 || n < 8) return false;                // whole 16-byte pieces
+    if (p.dimy < 4) return false;
+    if (n <= 64) return part_launch_z<16>(c, p);
+    if (n <= 128) return part_launch_z<32>(c, p);
+    if (n <= 256) return part_launch_z<64>(c, p);
+    return false;
+}
+static bool part_dispatch_z(fs3d_ctx *, const SweepParams<double> &) { return false; }
 
 // false: dims / precision / slab configuration not covered -> the caller falls back to the exact kernels
 template <typename R>
@@ -480,7 +856,7 @@ bool launch_sweep_part(fs3d_ctx *c, int dir, const SweepParams<R> &p)
     if (dir == 0 && (p.ghost_lo || p.ghost_hi)) return false;                            // X sweep of an x-slab: own path
     if (dir == 0) return part_dispatch_xy<R, 0>(c, p);
     if (dir == 1) return part_dispatch_xy<R, 1>(c, p);
-    return false;
+    return part_dispatch_z(c, p);
 }
 template bool launch_sweep_part<float>(fs3d_ctx *, int, const SweepParams<float> &);
 template bool launch_sweep_part<double>(fs3d_ctx *, int, const SweepParams<double> &);

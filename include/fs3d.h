@@ -58,7 +58,7 @@ enum {
                                  equations, different rounding -- equal to the CPU path to a stated tolerance
                                  (DESIGN.md section 5), not bit for bit; errors where it does not apply */
     FS3D_SWEEP_EXACT = 4      /* fastest of the bit-exact kernels (PIPE, its segmented form, LINE) */
-};
+};  /* environment FS3D_DEFAULT_KERNEL=<id> sets the initial value of FS3D_OPT_SWEEP_KERNEL for new contexts */
 enum {
     FS3D_OPT_SWEEP_KERNEL = 0,
     FS3D_OPT_FUSE_MERGE = 1,  /* 1 (default): merge fused into the sweep; 0: separate merge kernels */

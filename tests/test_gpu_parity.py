@@ -11,9 +11,16 @@ from cmc_fluid_solver_amd import capi, grids
 
 pytestmark = pytest.mark.gpu
 
+@pytest.fixture(autouse=True)
+def _exact_kernels(monkeypatch):
+    """These tests assert bit-equality with the CPU oracle: new contexts start on the bit-exact kernels
+    (FS3D_SWEEP_EXACT).  The partition kernels (the fp32 default) have their own tolerance tests in test_gpu_part.py."""
+    monkeypatch.setenv("FS3D_DEFAULT_KERNEL", "4")
+
+
 DT = 0.1
 PARAMS = (200.0, 0.72, 1.4)
-KERNELS = [capi.SWEEP_LINE, capi.SWEEP_PIPE]
+KERNELS = [capi.SWEEP_LINE, capi.SWEEP_PIPE]      # the bit-exact kernels; FS3D_SWEEP_PART: tests/test_gpu_part.py
 
 
 def _oracle():
@@ -21,7 +28,7 @@ def _oracle():
     return O
 
 
-def make_pair(g, dtype, kernel=capi.SWEEP_AUTO, fuse=1):
+def make_pair(g, dtype, kernel=capi.SWEEP_EXACT, fuse=1):
     O = _oracle()
     params = capi.fluid_params(dtype, *PARAMS)
     s = capi.Solver(g, params, dtype)
@@ -211,7 +218,7 @@ def test_long_lines_pipe_kernel(built, dims):
     lane tiles that are partly empty (70 = 64 + 6), obstacle inside: 2 steps, fp32, bit-exact."""
     O = _oracle()
     g = grids.box_with_obstacle(*dims, h=0.02)
-    s, o = make_pair(g, np.float32, capi.SWEEP_AUTO)
+    s, o = make_pair(g, np.float32, capi.SWEEP_EXACT)
     seed_state(s, o, g, np.float32)
     for d in range(3):
         s.sweep(d, DT, capi.LAYER_CUR, capi.LAYER_TEMP, capi.LAYER_NEXT, merge=True)
@@ -233,8 +240,8 @@ def test_pipe_kernel_is_really_used(built):
     with pytest.raises(capi.Fs3dError) as ei:
         s.sweep(2, DT, capi.LAYER_CUR, capi.LAYER_TEMP, capi.LAYER_NEXT)
     assert ei.value.status == capi.ERR_UNSUPPORTED
-    # AUTO falls back to the thread-per-line kernel and still matches
-    s2, o2 = make_pair(g, np.float32, capi.SWEEP_AUTO)
+    # EXACT falls back to the thread-per-line kernel and still matches
+    s2, o2 = make_pair(g, np.float32, capi.SWEEP_EXACT)
     O = _oracle()
     s2.sweep(2, DT, capi.LAYER_CUR, capi.LAYER_TEMP, capi.LAYER_NEXT)
     o2.sweep(2, DT, O.L_CUR, O.L_TEMP, O.L_NEXT)

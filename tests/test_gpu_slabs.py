@@ -12,6 +12,13 @@ from cmc_fluid_solver_amd.slab import slab_range
 
 pytestmark = pytest.mark.gpu
 
+@pytest.fixture(autouse=True)
+def _exact_kernels(monkeypatch):
+    """These tests assert bit-equality with the CPU oracle: new contexts start on the bit-exact kernels
+    (FS3D_SWEEP_EXACT).  The partition kernels (the fp32 default) have their own tolerance tests in test_gpu_part.py."""
+    monkeypatch.setenv("FS3D_DEFAULT_KERNEL", "4")
+
+
 DT = 0.1
 PARAMS = (200.0, 0.72, 1.4)
 

@@ -12,6 +12,14 @@ import pytest
 from cmc_fluid_solver_amd import build as B
 from cmc_fluid_solver_amd import capi, shape2d
 
+
+@pytest.fixture(autouse=True)
+def _exact_kernels(monkeypatch):
+    """These tests assert bit-equality with the CPU oracle: new contexts start on the bit-exact kernels
+    (FS3D_SWEEP_EXACT).  The partition kernels (the fp32 default) have their own tolerance tests in test_gpu_part.py."""
+    monkeypatch.setenv("FS3D_DEFAULT_KERNEL", "4")
+
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 INPUTS = os.path.join(HERE, "golden", "inputs")
 CASES = {"box_pipe": ("box_pipe_2D_data.txt", "box_pipe_2D_config.txt"),
