@@ -157,7 +157,11 @@ __global__ void __launch_bounds__(LT * NCH, WPS) k_sweep_part(SweepParams<R> p, 
     }
     // order 0: consecutive ids = consecutive rows/planes `o` of one lane tile; 1: = the lane tiles of one row/plane
     // (concurrently running workgroups then stream whole rows: DRAM page locality)
-    const bool x_nonb = order & 2, x_nore = order & 4;      // timing experiments only (wrong numbers): FS3D_PART_ORDER bits 1, 2
+    const bool x_nonb = order & 2, x_nore = order & 4;
+    if (order & 8) {                                      // experiment: the later waves of the workgroup first during P
+        const int wq = (t >> 6) * 4 / (LT * NCH / 64);
+        if (wq == 1) __builtin_amdgcn_s_setprio(1); else if (wq == 2) __builtin_amdgcn_s_setprio(2); else if (wq == 3) __builtin_amdgcn_s_setprio(3);
+    }      // timing experiments only (wrong numbers): FS3D_PART_ORDER bits 1, 2
     const int tile_id = (order & 1) ? lb % n_tiles : lb / n_o, o = (order & 1) ? lb / n_tiles : lb - tile_id * n_o;
 
     const int n = DIR == 0 ? p.dimx : p.dimy;
@@ -195,12 +199,44 @@ __global__ void __launch_bounds__(LT * NCH, WPS) k_sweep_part(SweepParams<R> p, 
     constexpr int NCP = (M + 7) / 8;
     unsigned cpack[NCP];
     unsigned inmask = 0, intmask = 0, segmask = 0;
+    int cwv[M];
     {
-        int cwv[M];
         unsigned s_c = (son / (unsigned)sizeof(R)) * 2u;
         const unsigned ssc = (ssb / (unsigned)sizeof(R)) * 2u;
 #pragma unroll
         for (int i = 0; i < M; i++) { cwv[i] = __builtin_amdgcn_raw_buffer_load_b16(rCode, vel * 2u, s_c, 0); s_c = opq_s(s_c + ssc); }
+    }
+    // the first loads of the P phase do not depend on the codes: in flight before the codes are waited for (one memory
+    // round trip less on the critical path of the workgroup)
+    struct CellLd { R tp[4], c[4], om, op, le; };        // le: the lane-axis neighbour of the tile's two edge lanes
+    // running scalar offsets, opaque from cell to cell: otherwise the offsets of all M cells are computed up front and
+    // held in (spilled) SGPRs
+    unsigned s_is = so0, s_nd = son;
+    const unsigned vo_edge = kk == 0 ? vo - (unsigned)sizeof(R) : (kk == LT - 1 ? vo + (unsigned)sizeof(R) : PART_OOB);
+    auto issue = [&](CellLd &L) __attribute__((always_inline)) {
+        const unsigned sc = s_is;
+        s_is = opq_s(s_is + ssb);
+#pragma unroll
+        for (int f = 0; f < 4; f++) L.tp[f] = PBuf<R>::ld(Ltmp, vo, sc + ssb + (unsigned)f * fsb);
+#pragma unroll
+        for (int f = 0; f < 4; f++) L.c[f] = PBuf<R>::ld(Lcur, vo, sc + (unsigned)f * fsb);
+        const unsigned sv = sc + (unsigned)DIR * fsb;
+        if (x_nonb) { L.om = L.op = L.le = L.c[0]; }
+        else {
+            L.om = PBuf<R>::ld(Ltmp, vo, sv - osb); L.op = PBuf<R>::ld(Ltmp, vo, sv + osb);
+            // lane-axis neighbours: the lanes next door hold them (DPP shifts below); only the tile's first and last lane
+            // fetch theirs from outside the tile -- every other lane of this load is out of range (no memory access)
+            L.le = PBuf<R>::ld(Ltmp, vo_edge, sv);
+        }
+    };
+    R Tm[4], Tc[4];
+#pragma unroll
+    for (int f = 0; f < 4; f++) { Tm[f] = PBuf<R>::ld(Ltmp, vo, so0 - ssb + (unsigned)f * fsb); Tc[f] = PBuf<R>::ld(Ltmp, vo, so0 + (unsigned)f * fsb); }
+    CellLd L[PF + 1];
+#pragma unroll
+    for (int i = 0; i < PF && i < M; i++) issue(L[i]);
+    __builtin_amdgcn_sched_barrier(0);
+    {
 #pragma unroll
         for (int i = 0; i < NCP; i++) cpack[i] = 0;
 #pragma unroll
@@ -238,30 +274,6 @@ __global__ void __launch_bounds__(LT * NCH, WPS) k_sweep_part(SweepParams<R> p, 
     // ---- P: rows -------------------------------------------------------------------------------------------
     R q[M], dU[M], dV[M], dW[M];
     {
-        struct CellLd { R tp[4], c[4], om, op, lm, lp; };
-        // running scalar offsets, opaque from cell to cell: otherwise the offsets of all M cells are computed up front and
-        // held in (spilled) SGPRs
-        unsigned s_is = so0, s_nd = son;
-        auto issue = [&](CellLd &L) __attribute__((always_inline)) {
-            const unsigned sc = s_is;
-            s_is = opq_s(s_is + ssb);
-#pragma unroll
-            for (int f = 0; f < 4; f++) L.tp[f] = PBuf<R>::ld(Ltmp, vo, sc + ssb + (unsigned)f * fsb);
-#pragma unroll
-            for (int f = 0; f < 4; f++) L.c[f] = PBuf<R>::ld(Lcur, vo, sc + (unsigned)f * fsb);
-            const unsigned sv = sc + (unsigned)DIR * fsb;
-            if (x_nonb) { L.om = L.op = L.lm = L.lp = L.c[0]; }
-            else {
-                L.om = PBuf<R>::ld(Ltmp, vo, sv - osb); L.op = PBuf<R>::ld(Ltmp, vo, sv + osb);
-                L.lm = PBuf<R>::ld(Ltmp, vo, sv - (unsigned)sizeof(R)); L.lp = PBuf<R>::ld(Ltmp, vo, sv + (unsigned)sizeof(R));
-            }
-        };
-        R Tm[4], Tc[4];
-#pragma unroll
-        for (int f = 0; f < 4; f++) { Tm[f] = PBuf<R>::ld(Ltmp, vo, so0 - ssb + (unsigned)f * fsb); Tc[f] = PBuf<R>::ld(Ltmp, vo, so0 + (unsigned)f * fsb); }
-        CellLd L[PF + 1];
-#pragma unroll
-        for (int i = 0; i < PF && i < M; i++) issue(L[i]);
         pstatic_for<M>([&](auto ic) __attribute__((always_inline)) {
             constexpr int i = decltype(ic)::value;
             if (i + PF < M) issue(L[(i + PF) % (PF + 1)]);
@@ -271,7 +283,14 @@ __global__ void __launch_bounds__(LT * NCH, WPS) k_sweep_part(SweepParams<R> p, 
             R g[4];
 #pragma unroll
             for (int f = 0; f < 4; f++) g[f] = pdivc(c.tp[f] - Tm[f], h2s, ir2s);          // d/ds of U, V, W, T (TimeLayer3D.h:338-340)
-            const R x1 = pdivc(c.op - c.om, h2o, ir2o), x2 = pdivc(c.lp - c.lm, h2l, ir2l);   // d(Vs)/d(o axis), d(Vs)/d(lane axis)
+            R lm, lp;                                             // Vs of the lanes next door (wave_shr:1 / wave_shl:1)
+            if (sizeof(R) == 4) {
+                const int cv = __builtin_bit_cast(int, (float)Tc[DIR]);
+                lm = (R)__builtin_bit_cast(float, __builtin_amdgcn_update_dpp(cv, cv, 0x138, 0xF, 0xF, false));
+                lp = (R)__builtin_bit_cast(float, __builtin_amdgcn_update_dpp(cv, cv, 0x130, 0xF, 0xF, false));
+            } else { lm = __shfl_up(Tc[DIR], 1, 64); lp = __shfl_down(Tc[DIR], 1, 64); }
+            lm = kk == 0 ? c.le : lm; lp = kk == LT - 1 ? c.le : lp;
+            const R x1 = pdivc(c.op - c.om, h2o, ir2o), x2 = pdivc(lp - lm, h2l, ir2l);   // d(Vs)/d(o axis), d(Vs)/d(lane axis)
             const R t0 = (DIR == 0 ? R(2) : R(1)) * g[0] * g[0], t1 = (DIR == 1 ? R(2) : R(1)) * g[1] * g[1], t2 = g[2] * g[2];
             const R diss = (((t0 + t1) + t2) + g[M1] * x1) + g[M2] * x2;          // DissFuncX/Y (TimeLayer3D.h:554-577)
             R dd[4];
@@ -301,6 +320,7 @@ __global__ void __launch_bounds__(LT * NCH, WPS) k_sweep_part(SweepParams<R> p, 
         });
     }
 
+    if (order & 8) __builtin_amdgcn_s_setprio(0);
     PSTAMP(2);
     // ---- E: chunk elimination -> interface coefficients ------------------------------------------------------
     // every use recomputes the coefficients from an opaque copy of q (4 operations) instead of keeping 6 x M values alive
