@@ -368,22 +368,34 @@ __global__ void __launch_bounds__(LT * NCH, WPS) k_sweep_part(SweepParams<R> p, 
         const int sys = t / LT;
         const R *const em = ex + (sys == 3 ? 5 * ES : 0) + kk;      // this system's matrix words
         R *const er = ex + (10 + sys) * ES + kk;                    // Dp (-> X), Gf at + 4*ES
-        R cpa[NCH], dpa[NCH];
+        // c', d' of the interface system: registers up to 16 chunks, LDS beyond (c' in an array of its own, d' over Dp)
+        constexpr bool RL = NCH > 16;
+        R cpa[RL ? 1 : NCH], dpa[RL ? 1 : NCH];
+        R *const cx = ex + PART_EXW * ES + sys * ES + kk;
         R cp = R(0), dp = R(0);
-#pragma unroll
-        for (int c = 0; c < NCH; c++) {
+        auto fwd = [&](int c) __attribute__((always_inline)) {
             const R lo = em[0 * ES + c * LT], bp = em[1 * ES + c * LT], cl = em[2 * ES + c * LT];
             R vf = R(0), wf = R(0), gf = R(0);
             if (c + 1 < NCH) { vf = em[3 * ES + (c + 1) * LT]; wf = em[4 * ES + (c + 1) * LT]; gf = er[4 * ES + (c + 1) * LT]; }
             const R di = pfma(-cl, vf, bp), up = -cl * wf, rhs = pfma(-cl, gf, er[c * LT]);
             const R den = pfma(-lo, cp, di), r = prcp(den);
             cp = pquot(up, den, r); dp = pquot(pfma(-lo, dp, rhs), den, r);
-            cpa[c] = cp; dpa[c] = dp;
-        }
-        R x = dpa[NCH - 1];
-        er[(NCH - 1) * LT] = x;
+        };
+        if (RL) {
+            // many chunks: a rolled loop, c' and d' through the LDS (unrolled, the reads of all chunks are hoisted and spill)
+#pragma nounroll
+            for (int c = 0; c < NCH; c++) { fwd(c); cx[c * LT] = cp; er[c * LT] = dp; }
+            R x = dp;
+#pragma nounroll
+            for (int c = NCH - 2; c >= 0; c--) { x = pfma(-cx[c * LT], x, er[c * LT]); er[c * LT] = x; }
+        } else {
 #pragma unroll
-        for (int c = NCH - 2; c >= 0; c--) { x = pfma(-cpa[c], x, dpa[c]); er[c * LT] = x; }
+            for (int c = 0; c < NCH; c++) { fwd(c); cpa[c] = cp; dpa[c] = dp; }
+            R x = dp;
+            er[(NCH - 1) * LT] = x;
+#pragma unroll
+            for (int c = NCH - 2; c >= 0; c--) { x = pfma(-cpa[c], x, dpa[c]); er[c * LT] = x; }
+        }
     }
     __syncthreads();
     PSTAMP(5);
@@ -481,7 +493,7 @@ static bool part_launch_xy(fs3d_ctx *c, const SweepParams<R> &p)
 {
     const int n_o = DIR == 0 ? p.dimy : p.dimx;
     const int n_tiles = (p.dimz + LT - 1) / LT;
-    const size_t lds = ((size_t)NCH * M * LT + (size_t)PART_EXW * NCH * LT) * sizeof(R);
+    const size_t lds = ((size_t)NCH * M * LT + (size_t)(PART_EXW + (NCH > 16 ? 4 : 0)) * NCH * LT) * sizeof(R);
     static std::atomic<unsigned long long> attr_set{0};
     const unsigned long long dev_bit = 1ull << (c->device & 63);
     if (!(attr_set.load() & dev_bit)) {

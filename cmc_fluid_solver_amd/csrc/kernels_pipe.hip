@@ -1150,7 +1150,9 @@ static bool run_segments(fs3d_ctx *c, SweepParams<R> p)
     const long long lines = (long long)n_o * la_len;
     if (c->seg_carry_lines < lines) {
         for (int i = 0; i < 2; i++) if (c->seg_carry[i]) { hipStreamSynchronize(c->stream); hipFree(c->seg_carry[i]); c->seg_carry[i] = nullptr; }
-        if (hipMalloc(&c->seg_carry[0], 6 * (size_t)lines * sizeof(R)) != hipSuccess) { c->err = "pipe segments: hipMalloc of the carries failed"; return false; }
+        // two forward carry arrays, used alternately: a bundle that asks for the full-division instance reads its carry_in
+        // a second time, after the first instance has stored the segment's own carries
+        if (hipMalloc(&c->seg_carry[0], 12 * (size_t)lines * sizeof(R)) != hipSuccess) { c->err = "pipe segments: hipMalloc of the carries failed"; return false; }
         if (hipMalloc(&c->seg_carry[1], 4 * (size_t)lines * sizeof(R)) != hipSuccess) return false;
         c->seg_carry_lines = lines;
     }
@@ -1160,7 +1162,8 @@ static bool run_segments(fs3d_ctx *c, SweepParams<R> p)
     for (int s = 0; s < nseg; s++) {
         p.seg_index = s;
         p.seg_begin = s * seg; p.seg_len = std::min(seg, n - s * seg);
-        p.carry_in = s > 0 ? (const R *)c->seg_carry[0] : nullptr; p.carry_out = (R *)c->seg_carry[0];
+        R *const fc[2] = {(R *)c->seg_carry[0], (R *)c->seg_carry[0] + 6 * lines};
+        p.carry_in = s > 0 ? (const R *)fc[(s - 1) & 1] : nullptr; p.carry_out = fc[s & 1];
         if (!launch_half<R, DIR, CH>(c, p, 1, 0, nb)) return false;
     }
     for (int s = nseg - 1; s >= 0; s--) {
