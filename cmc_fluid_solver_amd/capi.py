@@ -46,7 +46,9 @@ SYMBOLS = {
     "fs3d_comm_init": (_i, [_vp, _vp, _i, _i]),
     "fs3d_local_group_create": (_i, [_i, C.POINTER(_vp)]),
     "fs3d_local_group_destroy": (None, [_vp]),
+    "fs3d_local_group_abort": (None, [_vp]),
     "fs3d_comm_init_local": (_i, [_vp, _vp, _i]),
+    "fs3d_comm_abort": (_i, [_vp]),
     "fs3d_last_step_timing": (_i, [_vp, C.POINTER(C.c_float), C.POINTER(_i)]),
     "fs3d_enable_timing": (_i, [_vp, _i]),
     "fs3d_profile_sweep": (_i, [_vp, _i, _d, _i, _i, _i, C.POINTER(C.c_ulonglong), _i, C.POINTER(_i)]),
@@ -134,6 +136,9 @@ class Solver:
     def comm_init(self, unique_id, rank, nranks):
         buf = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
         self._chk(self.lib.fs3d_comm_init(self.h, buf, rank, nranks))
+
+    def comm_abort(self):
+        self._chk(self.lib.fs3d_comm_abort(self.h))
 
     def comm_init_local(self, group, rank):
         self._chk(self.lib.fs3d_comm_init_local(self.h, group.h, rank))
@@ -238,6 +243,10 @@ class LocalGroup:
                 out[r] = fn(r, self.solvers[r])
             except BaseException as e:      # noqa: BLE001 - re-raised below
                 exc[r] = e
+                try:
+                    self.solvers[r].comm_abort()        # the other slab threads return ERR_COMM instead of waiting for ever
+                except Exception:
+                    pass
         th = [threading.Thread(target=work, args=(r,)) for r in range(len(self.solvers))]
         for t in th:
             t.start()

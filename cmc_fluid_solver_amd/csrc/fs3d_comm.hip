@@ -41,6 +41,14 @@ extern "C" fs3d_status fs3d_local_group_create(int nranks, void **group_out)
 
 extern "C" void fs3d_local_group_destroy(void *group) { delete (fs3d_local_group *)group; }
 
+extern "C" void fs3d_local_group_abort(void *group)
+{
+    fs3d_local_group *g = (fs3d_local_group *)group;
+    if (!g) return;
+    { std::lock_guard<std::mutex> lk(g->m); g->broken = true; }
+    g->cv.notify_all();
+}
+
 extern "C" fs3d_status fs3d_comm_init_local(fs3d_ctx *c, void *group, int rank)
 {
     fs3d_local_group *g = (fs3d_local_group *)group;
@@ -163,6 +171,22 @@ extern "C" fs3d_status fs3d_comm_init(fs3d_ctx *c, const void *unique_id_128, in
     return FS3D_OK;
 }
 
+// A rank that cannot go on (an error in the middle of a multi-step exchange, a driver thread that threw) takes the group
+// down so that its peers return FS3D_ERR_COMM from their pending / next exchange instead of waiting for ever.
+extern "C" fs3d_status fs3d_comm_abort(fs3d_ctx *c)
+{
+    if (!c) return FS3D_ERR_INVALID;
+    if (c->local) {
+        fs3d_local_group *g = (fs3d_local_group *)c->local;
+        { std::lock_guard<std::mutex> lk(g->m); g->broken = true; }
+        g->cv.notify_all();
+    } else if (c->comm) {
+        ncclCommAbort((ncclComm_t)c->comm);
+        c->comm = nullptr;
+    }
+    return FS3D_OK;
+}
+
 void fs3d_comm_destroy(fs3d_ctx *c)
 {
     if (c && c->comm) { ncclCommDestroy((ncclComm_t)c->comm); c->comm = nullptr; }
@@ -178,8 +202,9 @@ static fs3d_status exec_group(fs3d_ctx *c, const std::vector<XOp> &ops)
     const ncclDataType_t dt = c->prec == FS3D_F32 ? ncclFloat : ncclDouble;
     NCCLCHK(c, ncclGroupStart());
     for (const XOp &o : ops) {
-        if (o.send) NCCLCHK(c, ncclSend(o.ptr, o.count, dt, o.peer, (ncclComm_t)c->comm, c->stream));
-        else NCCLCHK(c, ncclRecv(o.ptr, o.count, dt, o.peer, (ncclComm_t)c->comm, c->stream));
+        const ncclResult_t r = o.send ? ncclSend(o.ptr, o.count, dt, o.peer, (ncclComm_t)c->comm, c->stream)
+                                      : ncclRecv(o.ptr, o.count, dt, o.peer, (ncclComm_t)c->comm, c->stream);
+        if (r != ncclSuccess) { ncclGroupEnd(); return cfail(c, o.send ? "ncclSend" : "ncclRecv", r); }     // never leave the group open
     }
     NCCLCHK(c, ncclGroupEnd());
     return FS3D_OK;

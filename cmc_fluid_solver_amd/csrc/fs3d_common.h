@@ -60,6 +60,8 @@ struct SweepParams {
     long long carry_pitch;      // lines per value row of the carry arrays
     int fast_div;               // pipe kernel, fp32: constant divisors are in the range of the division core (kernels_pipe.hip)
     int merge;                  // 0: write next only; 1: also temp_out = merged; 2: merged twice (sweep merge + global merge)
+    int *errw;                  // device-visible error word (pinned host memory): bit 0 = a relay hand-over of the pipe kernel timed out
+    int test_drop;              // test hook (env FS3D_TEST_DROP_HANDOFF): one wave never signals its hand-over; the poll bound is short
     int store_next;             // pipe kernel, fused time step: 0 when a later local iteration overwrites `next` unread (only the merge uses x)
 };
 
@@ -116,6 +118,7 @@ struct fs3d_ctx {
     long long seg_carry_lines = 0;
     int *redo = nullptr;           // pipe kernel, fp32: per-bundle "compute again with full divisions" flags (all zero between sweeps)
     int redo_cap = 0;
+    int *errw_host = nullptr, *errw_dev = nullptr;   // pinned + mapped error word of the kernels (checked at every synchronisation)
     int rank = 0, nranks = 1;
     int xblocks = 4;               // line blocks of the cross-slab X sweep pipeline (env FS3D_XBLOCKS)
     std::string err;

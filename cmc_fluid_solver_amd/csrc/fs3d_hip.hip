@@ -181,6 +181,16 @@ static void rec_collect(fs3d_ctx *c)
     c->ev_used = 0; c->ev_class.clear();
 }
 
+// Device-side failures that cannot raise a HIP error (a relay hand-over of the pipe kernel that never arrived): the
+// kernels set a bit in the context's pinned error word; every entry point that synchronises the stream checks it, so
+// that wrong numbers are never returned with FS3D_OK (GPUplan.cpp:173-193: the reference throws on every device error).
+static fs3d_status check_device_errors(fs3d_ctx *c)
+{
+    if (!c->errw_host || *c->errw_host == 0) return FS3D_OK;
+    *c->errw_host = 0;
+    return fail(c, FS3D_ERR_HIP, "GPU " + std::to_string(c->device) + ": sweep kernel: a relay hand-over between waves timed out; the fields of this step are invalid");
+}
+
 // ---------------------------------------------------------------------------------
 // lifetime
 // ---------------------------------------------------------------------------------
@@ -226,6 +236,9 @@ extern "C" fs3d_status fs3d_create(fs3d_ctx **out, int device, fs3d_precision pr
     c->red_blocks = 1024;
     CK(hipMalloc((void **)&c->red_buf, sizeof(double) * 2 * (c->red_blocks + 1)));
     CK(hipHostMalloc((void **)&c->red_host, sizeof(double) * 2, hipHostMallocDefault));
+    CK(hipHostMalloc((void **)&c->errw_host, sizeof(int), hipHostMallocMapped));
+    *c->errw_host = 0;
+    CK(hipHostGetDevicePointer((void **)&c->errw_dev, c->errw_host, 0));
     CK(hipStreamSynchronize(c->stream));
 #undef CK
     *out = c;
@@ -250,6 +263,7 @@ extern "C" void fs3d_destroy(fs3d_ctx *c)
     if (c->red_buf) hipFree(c->red_buf);
     if (c->stamps) hipFree(c->stamps);
     if (c->red_host) hipHostFree(c->red_host);
+    if (c->errw_host) hipHostFree(c->errw_host);
     for (auto e : c->ev) hipEventDestroy(e);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -518,11 +532,14 @@ static void fill_params(fs3d_ctx *c, SweepParams<R> &p, int dir, double dt_, int
     p.merge = merge & 3;
     p.store_next = (merge & 4) ? 0 : 1;      // merge | 4: the caller never reads this sweep's `next` (time_step_enqueue)
     p.stamps = nullptr;
+    p.errw = c->errw_dev;
+    { const char *e = getenv("FS3D_TEST_DROP_HANDOFF"); p.test_drop = (e && atoi(e)) ? 1 : 0; }
     p.carry_in = nullptr; p.carry_out = nullptr; p.xcarry_in = nullptr; p.xcarry_out = nullptr; p.bundle0 = 0;
     p.seg_begin = 0; p.seg_len = 0; p.carry_pitch = c->plane; p.seg_index = 0; p.scr_bundles = 0;
     p.ghost_lo = c->x_offset > 0; p.ghost_hi = c->x_offset + c->dimx < c->dimx_global;
     // division core (fp32 pipe kernel): the constant divisors must be plain numbers in [2^-30, 2^60)
-    auto plain = [](double v) { v = v < 0 ? -v : v; return v >= 9.313225746154785e-10 && v < 1.152921504606847e18; };
+    // [2^-30, 2^26): with a divisor beyond 2^26 a tiny numerator gives a denormal quotient, which the core would double-round
+    auto plain = [](double v) { v = v < 0 ? -v : v; return v >= 9.313225746154785e-10 && v < 67108864.0; };
     p.fast_div = c->opt_div_core && plain((double)p.two_ds[0]) && plain((double)p.two_ds[1]) && plain((double)p.two_ds[2]) && plain((double)p.dt);
 }
 
@@ -561,11 +578,14 @@ static fs3d_status xsweep_multi(fs3d_ctx *c, SweepParams<R> &p)
     };
     p.carry_in = first ? nullptr : (const R *)c->carry[0]; p.carry_out = (R *)c->carry[1];
     p.xcarry_in = last ? nullptr : (const R *)c->carry[2]; p.xcarry_out = (R *)c->carry[3];
+    // a rank that fails in the middle of the pipeline must not leave its neighbours blocked in their receives: it
+    // aborts the group (fs3d_comm_abort), the peers' pending and later exchanges return FS3D_ERR_COMM
+    struct AbortOnError { fs3d_ctx *c; fs3d_status *st; ~AbortOnError() { if (*st != FS3D_OK) fs3d_comm_abort(c); } } guard{c, &st};
     for (int b = 0; b < nb; b++) {
         long long l0, l1; range(b, l0, l1);
         if (l1 <= l0) continue;
         if (!first && (st = fs3d_comm_xfer_rows(c, c->carry[0], 6, pl, l0, l1, c->rank - 1, false))) return st;
-        if (pipe) { if (!launch_xslab_pipe<R>(c, p, 1, (int)(l0 / 64), (int)(l1 / 64))) return fail(c, FS3D_ERR_HIP, "pipe kernel launch (forward half)"); }
+        if (pipe) { if (!launch_xslab_pipe<R>(c, p, 1, (int)(l0 / 64), (int)(l1 / 64))) return st = fail(c, FS3D_ERR_HIP, "pipe kernel launch (forward half)"); }
         else launch_xsweep_fwd<R>(c, p, first ? nullptr : c->carry[0], c->carry[1], l0, l1);
         if (!last && (st = fs3d_comm_xfer_rows(c, c->carry[1], 6, pl, l0, l1, c->rank + 1, true))) return st;
     }
@@ -573,7 +593,7 @@ static fs3d_status xsweep_multi(fs3d_ctx *c, SweepParams<R> &p)
         long long l0, l1; range(b, l0, l1);
         if (l1 <= l0) continue;
         if (!last && (st = fs3d_comm_xfer_rows(c, c->carry[2], 4, pl, l0, l1, c->rank + 1, false))) return st;
-        if (pipe) { if (!launch_xslab_pipe<R>(c, p, 2, (int)(l0 / 64), (int)(l1 / 64))) return fail(c, FS3D_ERR_HIP, "pipe kernel launch (backward half)"); }
+        if (pipe) { if (!launch_xslab_pipe<R>(c, p, 2, (int)(l0 / 64), (int)(l1 / 64))) return st = fail(c, FS3D_ERR_HIP, "pipe kernel launch (backward half)"); }
         else launch_xsweep_bwd<R>(c, p, last ? nullptr : c->carry[2], c->carry[3], l0, l1);
         if (!first && (st = fs3d_comm_xfer_rows(c, c->carry[3], 4, pl, l0, l1, c->rank - 1, true))) return st;
     }
@@ -767,7 +787,7 @@ extern "C" fs3d_status fs3d_sweep(fs3d_ctx *c, int dir, double dt, int l_cur, in
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->timing) rec_collect(c);
-    return FS3D_OK;
+    return check_device_errors(c);
 }
 
 extern "C" fs3d_status fs3d_merge(fs3d_ctx *c, int l_src, int l_dest)
@@ -863,6 +883,7 @@ extern "C" fs3d_status fs3d_time_step(fs3d_ctx *c, double dt, int G, int L, int 
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     if (c->timing) rec_collect(c);
+    if ((st = check_device_errors(c))) return st;
     if (err_out) *err_out = c->diffError;
     if (c->diffError > 0.01) {                                               // :371-374 (ERR_THRESHOLD, AdiSolver3D.h:32)
         char b[128]; snprintf(b, sizeof b, "Error is too big! %f", c->diffError);
@@ -900,7 +921,7 @@ extern "C" fs3d_status fs3d_synchronize(fs3d_ctx *c)
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->timing) rec_collect(c);
-    return FS3D_OK;
+    return check_device_errors(c);
 }
 
 // Solver3D::GetLayer, Solver3D.cpp:21-25

@@ -47,18 +47,23 @@ __device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make
 // Point-to-point hand-off between the waves of a workgroup through an LDS flag (the relay phases): the
 // producer publishes its data, then the flag; the consumer polls the flag, then reads.  DS operations of a wave
 // execute in order; the fences keep the compiler from moving accesses across the flag.  The poll is bounded:
-// a lost hand-off ends in wrong numbers (caught by the parity tests), never in a hung GPU.
+// a lost hand-off never hangs the GPU; it sets bit 0 of the context's error word (g_errw, pinned host memory), which
+// every synchronising entry point turns into FS3D_ERR_HIP -- wrong numbers are never returned as a success.
 // The flags are accessed through explicit LDS (address space 3) pointers: a volatile access through a generic
 // pointer is compiled to a FLAT instruction with system-scope cache bits and a vmcnt(0) wait behind it, several
 // times the latency of the ds_read / ds_write these turn into.
 typedef __attribute__((address_space(3))) volatile int lds_flag_t;
-__device__ __forceinline__ void flag_wait(volatile int *f_)
+struct FlagCtl { int *errw; int bound; };      // per-kernel: where a timed-out wait reports, and after how many polls
+__device__ __forceinline__ void flag_wait(volatile int *f_, const FlagCtl &fc)
 {
     lds_flag_t *f = (lds_flag_t *)f_;
     int guard = 0;
     while (__builtin_amdgcn_readfirstlane(*f) == 0) {
         __builtin_amdgcn_s_sleep(1);
-        if (++guard > (1 << 22)) break;
+        if (++guard > fc.bound) {
+            if (fc.errw && (threadIdx.x & 63) == 0) __hip_atomic_fetch_or(fc.errw, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
@@ -413,6 +418,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_sweep_pipe(SweepParams<R> p, int
     volatile int *bflag = fflag + 4 * NPIECE * NW;     // [NPIECE][NW]: backward step (h, w) is done
     volatile int *live_lds = bflag + NPIECE * NW;      // [NW][2]: lanes whose line has a solved or merged cell among the wave's cells
     if (threadIdx.x < 5 * NPIECE * NW) ((lds_flag_t *)fflag)[threadIdx.x] = 0;
+    const FlagCtl fctl = {p.errw, p.test_drop ? (1 << 10) : (1 << 22)};
     __syncthreads();                                        // the only workgroup-wide barrier of the kernel
     // The relay visits the waves in order, so the low waves are needed first: give them the issue slots first.
     // It also takes the waves out of lockstep (they would otherwise all wait for memory at the same time).
@@ -751,7 +757,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_sweep_pipe(SweepParams<R> p, int
     STAMP(1);
     __builtin_amdgcn_s_setprio(3);     // the serial chains are latency-critical: ahead of other waves' P/O work
     if (MODE != 2) {
-    if (w > 0) flag_wait(&fflag[3 * NPIECE * NW + w - 1]);
+    if (w > 0) flag_wait(&fflag[3 * NPIECE * NW + w - 1], fctl);
     STAMP(2);
 #define FWD_COEF(VAR, FASTC)                                                                              \
     {                                                                                                     \
@@ -774,7 +780,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_sweep_pipe(SweepParams<R> p, int
         /* step (H, w) follows (H, w-1), or (H-1, NW-1) for w = 0: the pieces in the order of the line */ \
         R cp = R(0), dp = R(0);                                                                           \
         if (w > 0 || H > 0) {                                                                             \
-            flag_wait(&fflag[(VAR * NPIECE + (w > 0 ? H : H - 1)) * NW + (w > 0 ? w - 1 : NW - 1)]); \
+            flag_wait(&fflag[(VAR * NPIECE + (w > 0 ? H : H - 1)) * NW + (w > 0 ? w - 1 : NW - 1)], fctl); \
             cp = relay[(2 * VAR) * 64 + lane]; dp = relay[(2 * VAR + 1) * 64 + lane];                     \
         } else if (MODE == 1 && p.carry_in && lane_valid) {                                               \
             /* the recurrence continues the slab below (k_xsweep_fwd's carry layout) */                  \
@@ -807,7 +813,8 @@ __global__ void __launch_bounds__(NW * 64, 2) k_sweep_pipe(SweepParams<R> p, int
             __builtin_amdgcn_sched_barrier(0);                                                            \
         }                                                                                                 \
         relay[(2 * VAR) * 64 + lane] = cp; relay[(2 * VAR + 1) * 64 + lane] = dp;                         \
-        flag_set(&fflag[(VAR * NPIECE + H) * NW + w]);                                               \
+        if (!(p.test_drop && blockIdx.x == 0 && w == 2 && VAR == 3 && H == 0))   /* test hook: a lost hand-over */ \
+            flag_set(&fflag[(VAR * NPIECE + H) * NW + w]);                                           \
     }
     static_for<NPIECE>([&](auto h_c) __attribute__((always_inline)) {
         constexpr int H = decltype(h_c)::value;
@@ -873,7 +880,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_sweep_pipe(SweepParams<R> p, int
 #pragma unroll
         for (int t = 0; t < PC; t++) { ctv[t] = myC[(H * PC + t) * 64]; e3v[t] = myD[(H * PC + t) * 64]; }
         if (w < NW - 1 || H < NPIECE - 1) {
-            flag_wait(&bflag[(w < NW - 1 ? H : H + 1) * NW + (w < NW - 1 ? w + 1 : 0)]);
+            flag_wait(&bflag[(w < NW - 1 ? H : H + 1) * NW + (w < NW - 1 ? w + 1 : 0)], fctl);
             x[0] = relay[0 * 64 + lane]; x[1] = relay[1 * 64 + lane];
             x[2] = relay[2 * 64 + lane]; x[3] = relay[3 * 64 + lane];
         } else if (MODE == 2 && p.xcarry_in && lane_valid) {

@@ -120,9 +120,16 @@ static int run(const std::string &data, const std::string &prefix, const fs3d::C
 // Results equal the single-GPU run's value for value.  Slab r runs on device r, or all on device 0 with --same-device.
 namespace {
 struct Barrier {
-    std::mutex m; std::condition_variable cv; int n, waiting = 0; long gen = 0;
+    std::mutex m; std::condition_variable cv; int n, waiting = 0; long gen = 0; bool broken = false;
     explicit Barrier(int n_) : n(n_) {}
-    void wait() { std::unique_lock<std::mutex> lk(m); const long g = gen; if (++waiting == n) { waiting = 0; gen++; cv.notify_all(); } else cv.wait(lk, [&] { return gen != g; }); }
+    void wait()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        const long g = gen;
+        if (++waiting == n) { waiting = 0; gen++; cv.notify_all(); } else cv.wait(lk, [&] { return gen != g || broken; });
+        if (broken) throw std::runtime_error("another slab thread failed");
+    }
+    void abort() { { std::lock_guard<std::mutex> lk(m); broken = true; } cv.notify_all(); }
 };
 }
 
@@ -182,10 +189,19 @@ static int run_slabs(const fs3d::Grid3D<FTYPE> &grid, const fs3d::Grid2D &g2, co
                     }
                 }
                 if (r == 0) steps_done = steps;
-            } catch (...) { errs[r] = std::current_exception(); }
+            } catch (...) {
+                // release the other slab threads: they wait for this one in the transport (halo planes, carries) or at the
+                // output barrier and would never return
+                errs[r] = std::current_exception();
+                fs3d_local_group_abort(group);
+                bar.abort();
+            }
         });
     for (auto &t : th) t.join();
     AdiSolver3D<FTYPE>::DestroyLocalGroup(group);
+    for (auto &e : errs) if (e) {          // the first failure, not the "another slab thread failed" it caused
+        try { std::rethrow_exception(e); } catch (std::exception &x) { if (std::string(x.what()).find("another slab thread") == std::string::npos && std::string(x.what()).find("a peer failed") == std::string::npos) throw; } catch (...) { throw; }
+    }
     for (auto &e : errs) if (e) std::rethrow_exception(e);
     const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     (void)csv;

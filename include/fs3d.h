@@ -171,7 +171,15 @@ fs3d_status fs3d_comm_init(fs3d_ctx *ctx, const void *unique_id_128, int rank, i
  * slab protocol on a single card).  Destroy the contexts before the group. */
 fs3d_status fs3d_local_group_create(int nranks, void **group_out);
 void fs3d_local_group_destroy(void *group);
+/* a driver thread that fails before it holds a context (Init threw) releases the others: every member's pending and later
+ * exchange returns FS3D_ERR_COMM */
+void fs3d_local_group_abort(void *group);
 fs3d_status fs3d_comm_init_local(fs3d_ctx *ctx, void *group, int rank);
+/* A rank / slab thread that cannot go on (its own call failed, its driver thread threw) takes the group down: the peers'
+ * pending and later exchanges return FS3D_ERR_COMM instead of blocking (the reference: gpuSafeCall / mpiSafeCall throw,
+ * main catches and calls MPI_Abort, GPUplan.cpp:173-193, FluidSolver3D.cpp:272-283).  The library calls it itself when a
+ * multi-step exchange (the cross-slab X sweep) fails half way. */
+fs3d_status fs3d_comm_abort(fs3d_ctx *ctx);
 
 /* ---- measurement ---------------------------------------------------------------
  * Wall time of the kernels of the last fs3d_time_step* call, measured with HIP events
