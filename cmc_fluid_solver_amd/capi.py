@@ -19,7 +19,8 @@ DIR_X, DIR_Y, DIR_Z = 0, 1, 2
 LAYER_CUR, LAYER_TEMP, LAYER_HALF, LAYER_NEXT = 0, 1, 2, 3
 SWEEP_AUTO, SWEEP_LINE, SWEEP_PIPE, SWEEP_PART, SWEEP_EXACT = 0, 1, 2, 3, 4
 KERNEL_NAMES = {0: "none", 1: "line", 2: "pipe", 3: "part"}
-OPT_SWEEP_KERNEL, OPT_FUSE_MERGE, OPT_DIV_CORE = 0, 1, 2
+OPT_SWEEP_KERNEL, OPT_FUSE_MERGE, OPT_DIV_CORE, OPT_XSOLVE = 0, 1, 2, 3
+XSOLVE_AUTO, XSOLVE_PIPELINED, XSOLVE_REDUCED = 0, 1, 2
 
 # every symbol include/fs3d.h declares: name -> (restype, argtypes)
 _vp, _i, _d = C.c_void_p, C.c_int, C.c_double
@@ -204,7 +205,8 @@ class Solver:
         for d, nm in enumerate("XYZ"):
             k, sg = C.c_int(0), C.c_int(0)
             self._chk(self.lib.fs3d_last_sweep_kernel(self.h, d, C.byref(k), C.byref(sg)))
-            out[nm] = KERNEL_NAMES.get(k.value, str(k.value)) + ("-segmented" if sg.value else "")
+            out[nm] = KERNEL_NAMES.get(k.value, str(k.value)) + ("-segmented" if sg.value & 1 else "") + \
+                {0: "", 1: "+pipelined-ranks", 2: "+reduced-interface"}[(sg.value >> 1) & 3]
         return out
 
     def enable_timing(self, on=True):

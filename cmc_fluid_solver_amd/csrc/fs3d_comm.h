@@ -11,3 +11,6 @@ fs3d_status fs3d_comm_halo_exchange(fs3d_ctx *c, int buf, int nfields);
 fs3d_status fs3d_comm_allreduce_sum2(fs3d_ctx *c, double *dev2);
 // one grouped transfer of elements [l0,l1) of each of `nrows` rows (row pitch `pitch` elements) to/from `peer`
 fs3d_status fs3d_comm_xfer_rows(fs3d_ctx *c, void *dev, int nrows, size_t pitch, long long l0, long long l1, int peer, bool send);
+// all-gather of `count` elements per rank: recv = [rank][count] (send may not alias recv); one grouped exchange
+fs3d_status fs3d_comm_allgather(fs3d_ctx *c, const void *send, void *recv, size_t count);
+extern "C" fs3d_status fs3d_comm_abort(fs3d_ctx *c);

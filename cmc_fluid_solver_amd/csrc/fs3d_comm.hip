@@ -244,3 +244,23 @@ fs3d_status fs3d_comm_xfer_rows(fs3d_ctx *c, void *dev, int nrows, size_t pitch,
         ops.push_back({(char *)dev + ((size_t)r * pitch + (size_t)l0) * c->esize, (size_t)(l1 - l0), peer, send});
     return exec_group(c, ops);
 }
+
+fs3d_status fs3d_comm_allgather(fs3d_ctx *c, const void *send, void *recv, size_t count)
+{
+    if (hipMemcpyAsync((char *)recv + (size_t)c->rank * count * c->esize, send, count * c->esize, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) {
+        c->err = "all-gather: device copy of the own block failed"; return FS3D_ERR_HIP;
+    }
+    if (c->nranks == 1) return FS3D_OK;
+    if (!c->local && c->comm) {
+        const ncclDataType_t dt = c->prec == FS3D_F32 ? ncclFloat : ncclDouble;
+        NCCLCHK(c, ncclAllGather(send, recv, count, dt, (ncclComm_t)c->comm, c->stream));
+        return FS3D_OK;
+    }
+    std::vector<XOp> ops;
+    for (int r = 0; r < c->nranks; r++) {
+        if (r == c->rank) continue;
+        ops.push_back({(void *)send, count, r, true});
+        ops.push_back({(char *)recv + (size_t)r * count * c->esize, count, r, false});
+    }
+    return exec_group(c, ops);
+}

@@ -120,6 +120,9 @@ struct fs3d_ctx {
     int redo_cap = 0;
     int *errw_host = nullptr, *errw_dev = nullptr;   // pinned + mapped error word of the kernels (checked at every synchronisation)
     int rank = 0, nranks = 1;
+    void *xif_send = nullptr, *xif_all = nullptr;   // reduced-interface X sweep: this slab's 18 words per line / all ranks'
+    int opt_xsolve = 0;            // FS3D_OPT_XSOLVE: 0 auto, 1 pipelined (bit-exact), 2 reduced interface
+    int ran_xsolve = 0;            // what the last cross-slab X sweep ran: 1 pipelined, 2 reduced interface
     int xblocks = 4;               // line blocks of the cross-slab X sweep pipeline (env FS3D_XBLOCKS)
     std::string err;
 };
@@ -135,4 +138,7 @@ template <typename R> bool launch_xslab_pipe(fs3d_ctx *c, SweepParams<R> p, int 
 // lines longer than the pipe kernel holds: the sweep as a sequence of segment halves on one GPU; false: unsupported
 template <typename R> bool launch_sweep_pipe_segmented(fs3d_ctx *c, int dir, SweepParams<R> p);
 template <typename R> void launch_xsweep_fwd(fs3d_ctx *c, const SweepParams<R> &p, const void *carry_in, void *carry_out, long long l0, long long l1);
+// reduced-interface cross-slab X sweep: interface coefficients of this slab (18 words per line), the R x R interface solve
+template <typename R> void launch_xiface(fs3d_ctx *c, const SweepParams<R> &p, void *out);
+template <typename R> void launch_xreduce(fs3d_ctx *c, const void *all, long long nl, int nranks, int me, void *carry_in, void *xcarry_in);
 template <typename R> void launch_xsweep_bwd(fs3d_ctx *c, const SweepParams<R> &p, const void *xcarry_in, void *xcarry_out, long long l0, long long l1);

@@ -258,6 +258,8 @@ extern "C" void fs3d_destroy(fs3d_ctx *c)
     for (int d = 0; d < 3; d++) if (c->dead[d]) hipFree(c->dead[d]);
     if (c->node) hipFree(c->node);
     if (c->scr) hipFree(c->scr);
+    if (c->xif_send) hipFree(c->xif_send);
+    if (c->xif_all) hipFree(c->xif_all);
     for (int v = 0; v < 4; v++) if (c->bnd_val[v]) hipFree(c->bnd_val[v]);
     if (c->bnd_idx) hipFree(c->bnd_idx);
     if (c->red_buf) hipFree(c->red_buf);
@@ -285,6 +287,9 @@ extern "C" fs3d_status fs3d_set_option(fs3d_ctx *c, int option, int value)
         c->opt_kernel = value; return FS3D_OK;
     case FS3D_OPT_FUSE_MERGE: c->opt_fuse = value ? 1 : 0; return FS3D_OK;
     case FS3D_OPT_DIV_CORE: c->opt_div_core = value ? 1 : 0; return FS3D_OK;
+    case FS3D_OPT_XSOLVE:
+        if (value < 0 || value > 2) return fail(c, FS3D_ERR_INVALID, "bad cross-slab X solve id");
+        c->opt_xsolve = value; return FS3D_OK;
     default: return fail(c, FS3D_ERR_INVALID, "unknown option");
     }
 }
@@ -600,6 +605,42 @@ static fs3d_status xsweep_multi(fs3d_ctx *c, SweepParams<R> &p)
     return FS3D_OK;
 }
 
+// Cross-slab X sweep, reduced-interface form (kernels_line.hip: k_xiface / k_xreduce): every rank eliminates its slab at
+// once, ONE all-gather of 18 words per line, then the slab's halves run with the two boundary values given -- all lines
+// in one launch each, no pipeline over the ranks.
+template <typename R>
+static fs3d_status xsweep_reduced(fs3d_ctx *c, SweepParams<R> &p)
+{
+    fs3d_status st = ensure_scratch(c);
+    if (st) return st;
+    p.scr_ = (R *)c->scr;
+    const size_t pl = (size_t)c->plane;
+    if (!c->carry[0]) {
+        HIPCHK(c, hipMalloc(&c->carry[0], 6 * pl * c->esize)); HIPCHK(c, hipMalloc(&c->carry[1], 6 * pl * c->esize));
+        HIPCHK(c, hipMalloc(&c->carry[2], 4 * pl * c->esize)); HIPCHK(c, hipMalloc(&c->carry[3], 4 * pl * c->esize));
+    }
+    if (!c->xif_send) {
+        HIPCHK(c, hipMalloc(&c->xif_send, 18 * pl * c->esize));
+        HIPCHK(c, hipMalloc(&c->xif_all, (size_t)c->nranks * 18 * pl * c->esize));
+    }
+    struct AbortOnError { fs3d_ctx *c; fs3d_status *st; ~AbortOnError() { if (*st != FS3D_OK) fs3d_comm_abort(c); } } guard{c, &st};
+    launch_xiface<R>(c, p, c->xif_send);
+    if ((st = fs3d_comm_allgather(c, c->xif_send, c->xif_all, 18 * pl))) return st;
+    launch_xreduce<R>(c, c->xif_all, (long long)pl, c->nranks, c->rank, c->carry[0], c->carry[2]);
+    const bool pipe = c->opt_kernel != FS3D_SWEEP_LINE && xslab_pipe_supported<R>(p);
+    c->ran_kernel[0] = pipe ? FS3D_SWEEP_PIPE : FS3D_SWEEP_LINE; c->ran_segmented[0] = 1; c->ran_xsolve = 2;
+    p.carry_in = (const R *)c->carry[0]; p.carry_out = (R *)c->carry[1];
+    p.xcarry_in = (const R *)c->carry[2]; p.xcarry_out = (R *)c->carry[3];
+    if (pipe) {
+        if (!launch_xslab_pipe<R>(c, p, 1, 0, (int)(pl / 64))) return st = fail(c, FS3D_ERR_HIP, "pipe kernel launch (forward half)");
+        if (!launch_xslab_pipe<R>(c, p, 2, 0, (int)(pl / 64))) return st = fail(c, FS3D_ERR_HIP, "pipe kernel launch (backward half)");
+    } else {
+        launch_xsweep_fwd<R>(c, p, c->carry[0], c->carry[1], 0, (long long)pl);
+        launch_xsweep_bwd<R>(c, p, c->carry[2], c->carry[3], 0, (long long)pl);
+    }
+    return FS3D_OK;
+}
+
 // one sweep on explicit buffers; merge: 0 none, 1 fused merge, 2 fused merge twice
 template <typename R>
 static fs3d_status sweep_buffers(fs3d_ctx *c, int dir, double dt, int b_cur, int b_temp, int b_next, int b_tout, int merge)
@@ -608,7 +649,9 @@ static fs3d_status sweep_buffers(fs3d_ctx *c, int dir, double dt, int b_cur, int
     fill_params<R>(c, p, dir, dt, b_cur, b_temp, b_next, b_tout, merge);
     rec_begin(c, dir == 2 ? 0 : (dir == 1 ? 1 : 2));
     if (dir == 0 && c->nranks > 1) {
-        fs3d_status st = xsweep_multi<R>(c, p);
+        // reduced-interface form (all ranks at once) unless bit-equality with the sequential recurrence was asked for
+        const bool reduced = c->opt_xsolve == 2 || (c->opt_xsolve == 0 && (c->opt_kernel == FS3D_SWEEP_AUTO || c->opt_kernel == FS3D_SWEEP_PART));
+        fs3d_status st = reduced ? xsweep_reduced<R>(c, p) : xsweep_multi<R>(c, p);
         rec_end(c);
         if (st) return st;
         HIPCHK(c, hipGetLastError());
@@ -911,7 +954,7 @@ extern "C" fs3d_status fs3d_last_sweep_kernel(fs3d_ctx *c, int dir, int *kernel_
 {
     if (!c || dir < 0 || dir > 2 || !kernel_out) return FS3D_ERR_INVALID;
     *kernel_out = c->ran_kernel[dir];
-    if (segmented_out) *segmented_out = c->ran_segmented[dir];
+    if (segmented_out) *segmented_out = c->ran_segmented[dir] | (dir == 0 ? c->ran_xsolve << 1 : 0);
     return FS3D_OK;
 }
 

@@ -178,3 +178,116 @@ template void launch_xsweep_fwd<float>(fs3d_ctx *, const SweepParams<float> &, c
 template void launch_xsweep_fwd<double>(fs3d_ctx *, const SweepParams<double> &, const void *, void *, long long, long long);
 template void launch_xsweep_bwd<float>(fs3d_ctx *, const SweepParams<float> &, const void *, void *, long long, long long);
 template void launch_xsweep_bwd<double>(fs3d_ctx *, const SweepParams<double> &, const void *, void *, long long, long long);
+
+// ---------------------------------------------------------------------------------------------
+// Cross-slab X sweep, reduced-interface form (all ranks at once; cmc_fluid_solver_amd/partition.py with one chunk
+// per x-slab).  The reference pipelines the recurrence rank by rank (AdiSolver3D.cu:524-640): rank r cannot start
+// before rank r-1 has finished.  Here every rank eliminates the planes of its slab at the same time:
+//   k_xiface    per line: down- and up-sweep over the slab's cells before its last plane -> the interface row of
+//               the last plane (A, Bp, cl, Dp) and x_first = Gf - Vf X_{r-1} - Wf X_r, 18 words per line;
+//   all-gather  of those 18 words per line (the only exchange of the sweep);
+//   k_xreduce   per line: the R x R interface system (R = ranks), then for THIS rank the value just below its slab
+//               (X_{r-1}) and just above it (x_first of rank r+1) -- written in the carry layout of the halves;
+//   the existing halves (k_xsweep_fwd / k_xsweep_bwd, or the pipe kernel's MODE 1 / 2) solve the slab with those
+//   two values given, all lines at once, no further exchange.
+// Same equations as the pipelined form, algebraically exact; the rounding of the interface solve differs (results
+// equal the single-GPU fields to rounding, not bit for bit; the pipelined form stays available, FS3D_OPT_XSOLVE).
+template <typename R>
+__device__ __forceinline__ void xrow(const SweepParams<R> &p, long long idx, RowUVWT<R> &r)
+{
+    const int code = p.code[idx] & 0xF, kind = code & 3;
+    if (kind == ROW_INTERIOR) build_interior_row<R, 0>(p, idx, r);
+    else if (kind != ROW_SKIP) build_bc_row<R>(p, idx, code, r);
+    else { r.a_v = r.c_v = r.a_t = r.c_t = R(0); r.b_v = r.b_t = R(1); r.d[0] = r.d[1] = r.d[2] = r.d[3] = R(0); }
+    if (kind == ROW_END) { r.c_v = R(0); r.c_t = R(0); }       // Algorithms.h:23
+    if (kind == ROW_START) { r.a_v = R(0); r.a_t = R(0); }
+}
+
+#define XIFACE_WORDS 18
+template <typename R>
+__global__ void __launch_bounds__(256) k_xiface(SweepParams<R> p, R *out)
+{
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long nl = p.plane;
+    if (tid >= nl) return;
+    const int n = p.dimx;
+    RowUVWT<R> r;
+    // down: x[n-2] = dp - lp X_{r-1} - cp X_r
+    R cpv = R(0), lpv = R(-1), cpt = R(0), lpt = R(-1), dp[4] = {R(0), R(0), R(0), R(0)};
+    for (int s = 0; s < n - 1; s++) {
+        xrow<R>(p, tid + s * p.plane, r);
+        const R dv = r.b_v - r.a_v * cpv, dt = r.b_t - r.a_t * cpt;
+        dp[0] = (r.d[0] - r.a_v * dp[0]) / dv; dp[1] = (r.d[1] - r.a_v * dp[1]) / dv; dp[2] = (r.d[2] - r.a_v * dp[2]) / dv;
+        dp[3] = (r.d[3] - r.a_t * dp[3]) / dt;
+        lpv = -r.a_v * lpv / dv; lpt = -r.a_t * lpt / dt;
+        cpv = r.c_v / dv; cpt = r.c_t / dt;
+    }
+    // up: x[0] = ep - ap X_{r-1} - up X_r
+    R apv = R(0), upv = R(-1), apt = R(0), upt = R(-1), ep[4] = {R(0), R(0), R(0), R(0)};
+    for (int s = n - 2; s >= 0; s--) {
+        xrow<R>(p, tid + s * p.plane, r);
+        const R dv = r.b_v - r.c_v * apv, dt = r.b_t - r.c_t * apt;
+        ep[0] = (r.d[0] - r.c_v * ep[0]) / dv; ep[1] = (r.d[1] - r.c_v * ep[1]) / dv; ep[2] = (r.d[2] - r.c_v * ep[2]) / dv;
+        ep[3] = (r.d[3] - r.c_t * ep[3]) / dt;
+        upv = -r.c_v * upv / dv; upt = -r.c_t * upt / dt;
+        apv = r.a_v / dv; apt = r.a_t / dt;
+    }
+    xrow<R>(p, tid + (long long)(n - 1) * p.plane, r);
+    R *o = out + tid;
+    o[0 * nl] = -r.a_v * lpv; o[1 * nl] = r.b_v - r.a_v * cpv; o[2 * nl] = r.c_v; o[3 * nl] = apv; o[4 * nl] = upv;
+    o[5 * nl] = -r.a_t * lpt; o[6 * nl] = r.b_t - r.a_t * cpt; o[7 * nl] = r.c_t; o[8 * nl] = apt; o[9 * nl] = upt;
+    o[10 * nl] = r.d[0] - r.a_v * dp[0]; o[11 * nl] = r.d[1] - r.a_v * dp[1]; o[12 * nl] = r.d[2] - r.a_v * dp[2]; o[13 * nl] = r.d[3] - r.a_t * dp[3];
+    o[14 * nl] = ep[0]; o[15 * nl] = ep[1]; o[16 * nl] = ep[2]; o[17 * nl] = ep[3];
+}
+
+#define XREDUCE_MAXR 64
+template <typename R>
+__global__ void __launch_bounds__(256) k_xreduce(const R *all, long long nl, int nranks, int me, R *carry_in, R *xcarry_in)
+{
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= nl) return;
+    const long long rs = (long long)XIFACE_WORDS * nl;          // one rank's block
+    auto W = [&](int r, int w) { return all[r * rs + w * nl + tid]; };
+    R xl[4], xr[4];
+    for (int sys = 0; sys < 4; sys++) {
+        const int m = sys == 3 ? 5 : 0;
+        R cp[XREDUCE_MAXR], dq[XREDUCE_MAXR];
+        R c_ = R(0), d_ = R(0);
+        for (int r = 0; r < nranks; r++) {
+            const R lo = W(r, m + 0), cl = W(r, m + 2);
+            R di = W(r, m + 1), up = R(0), rhs = W(r, 10 + sys);
+            if (r + 1 < nranks) { di = di - cl * W(r + 1, m + 3); up = -cl * W(r + 1, m + 4); rhs = rhs - cl * W(r + 1, 14 + sys); }
+            const R den = di - lo * c_;
+            c_ = up / den; d_ = (rhs - lo * d_) / den;
+            cp[r] = c_; dq[r] = d_;
+        }
+        R x = dq[nranks - 1], xme = R(0), xabove = R(0), xbelow = R(0);
+        for (int r = nranks - 1; r >= 0; r--) {
+            if (r < nranks - 1) x = dq[r] - cp[r] * x;
+            if (r == me + 1) xabove = x;
+            if (r == me) xme = x;
+            if (r == me - 1) xbelow = x;
+        }
+        xl[sys] = me > 0 ? xbelow : R(0);
+        // the first cell of the slab above: Gf - Vf X_me - Wf X_{me+1}
+        xr[sys] = me + 1 < nranks ? W(me + 1, 14 + sys) - W(me + 1, m + 3) * xme - W(me + 1, m + 4) * xabove : R(0);
+    }
+    // carry layouts of the halves: forward [c'_uvw, c'_T, d'_U, d'_V, d'_W, d'_T] = [0, 0, X_{r-1}]; backward [x_U .. x_T]
+    carry_in[0 * nl + tid] = R(0); carry_in[1 * nl + tid] = R(0);
+    for (int k = 0; k < 4; k++) { carry_in[(2 + k) * nl + tid] = xl[k]; xcarry_in[k * nl + tid] = xr[k]; }
+}
+
+template <typename R>
+void launch_xiface(fs3d_ctx *c, const SweepParams<R> &p, void *out)
+{
+    hipLaunchKernelGGL((k_xiface<R>), dim3((unsigned)((p.plane + 63) / 64)), dim3(64), 0, c->stream, p, (R *)out);
+}
+template <typename R>
+void launch_xreduce(fs3d_ctx *c, const void *all, long long nl, int nranks, int me, void *carry_in, void *xcarry_in)
+{
+    hipLaunchKernelGGL((k_xreduce<R>), dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, c->stream, (const R *)all, nl, nranks, me, (R *)carry_in, (R *)xcarry_in);
+}
+template void launch_xiface<float>(fs3d_ctx *, const SweepParams<float> &, void *);
+template void launch_xiface<double>(fs3d_ctx *, const SweepParams<double> &, void *);
+template void launch_xreduce<float>(fs3d_ctx *, const void *, long long, int, int, void *, void *);
+template void launch_xreduce<double>(fs3d_ctx *, const void *, long long, int, int, void *, void *);

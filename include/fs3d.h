@@ -62,6 +62,10 @@ enum {
 enum {
     FS3D_OPT_SWEEP_KERNEL = 0,
     FS3D_OPT_FUSE_MERGE = 1,  /* 1 (default): merge fused into the sweep; 0: separate merge kernels */
+    FS3D_OPT_XSOLVE = 3,      /* cross-slab X sweep of a multi-GPU group: 1 = pipelined over the ranks (the reference's form,
+                                 AdiSolver3D.cu:524-640; bit-equal to one GPU), 2 = reduced interface (every rank eliminates its slab
+                                 at once, one all-gather per sweep; equal to one GPU to rounding), 0 (default) = 2 unless the
+                                 sweep-kernel option asks for the bit-exact kernels */
     FS3D_OPT_DIV_CORE = 2     /* 1 (default): fp32 pipe kernel divides with the scaling-free core of the IEEE expansion and
                                  falls back to the full division where an operand needs scaling (same results); 0: always full */
 };
@@ -198,7 +202,8 @@ fs3d_status fs3d_profile_sweep(fs3d_ctx *ctx, int dir, double dt, int l_cur, int
                                unsigned long long *stamps_out, int max_blocks, int *n_blocks_out);
 
 /* Which kernel the last sweep of direction dir (FS3D_DIR_*) really ran: FS3D_SWEEP_LINE / _PIPE / _PART, with
- * *segmented_out (optional) = 1 when PIPE ran as segment halves through the HBM scratch.  0 = no sweep yet.
+ * *segmented_out (optional): bit 0 = PIPE / LINE ran as halves through the HBM scratch (long lines, x-slabs); for dir X
+ * of a multi-GPU group bits 1-2 = the cross-slab form that ran (1 pipelined, 2 reduced interface).  0 = no sweep yet.
  * FS3D_SWEEP_AUTO never falls back silently: callers (bench.py, fs3d_run) print this. */
 fs3d_status fs3d_last_sweep_kernel(fs3d_ctx *ctx, int dir, int *kernel_out, int *segmented_out);
 

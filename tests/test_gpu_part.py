@@ -347,3 +347,95 @@ def test_masked_geometry_256(built):
     _yardstick(A, B, C, "256^3 masked geometry after 2 steps")
     for a, b in zip(ea, eb):
         assert a == pytest.approx(b, rel=1e-4)
+
+
+# ---- cross-slab X sweep, reduced-interface form (all ranks at once, one all-gather per sweep) -----------------------
+@pytest.mark.parametrize("nranks", [2, 3, 4, 8])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_slabs_reduced_interface_x_solve(built, nranks, dtype):
+    """x-slabs through the in-process group (what the RCCL ranks run, minus the wire): the reduced-interface X solve
+    (AdiSolver3D.cu:524-640 replaced: every rank eliminates its slab at once) against ONE context on the same kernels
+    otherwise -- single sweeps on a seeded state and three time steps.  Equal to rounding (the interface solve rounds
+    differently from the sequential recurrence): the fp64 run shows how close 'rounding' is."""
+    O = _oracle()
+    g = grids.box_with_obstacle(67, 24, 64, h=0.02)              # uneven slabs, an obstacle across slab boundaries
+    params = capi.fluid_params(dtype, *PARAMS)
+    base = [np.ascontiguousarray(a, dtype) for a in (g.vx, g.vy, g.vz, g.T)]
+    cur, tmp = grids.perturb(base, seed=3), grids.perturb(base, seed=4)
+    from cmc_fluid_solver_amd.slab import slab_range
+
+    def single():
+        s = capi.Solver(g, params, dtype)
+        s.set_option(capi.OPT_SWEEP_KERNEL, capi.SWEEP_EXACT)
+        s.upload_layer(capi.LAYER_CUR, cur); s.upload_layer(capi.LAYER_TEMP, tmp)
+        s.sweep(0, DT, capi.LAYER_CUR, capi.LAYER_TEMP, capi.LAYER_NEXT, merge=True)
+        sw = s.download_layer(capi.LAYER_NEXT), s.download_layer(capi.LAYER_TEMP)
+        s.close()
+        s = capi.Solver(g, params, dtype)
+        s.set_option(capi.OPT_SWEEP_KERNEL, capi.SWEEP_EXACT)
+        errs = []
+        for i in range(3):
+            s.UpdateBoundaries(); errs.append(s.TimeStep(DT, 4, 2, True))
+        out = sw, s.download_layer(capi.LAYER_CUR), errs
+        s.close()
+        return out
+    (ref_next, ref_temp), ref_cur, ref_errs = single()
+
+    grp = capi.LocalGroup(g, params, nranks, dtype)
+
+    def work(r, sv):
+        x0, x1 = slab_range(g.dimx, r, nranks)
+        sv.set_option(capi.OPT_SWEEP_KERNEL, capi.SWEEP_EXACT)          # the slab-local kernels as in the single run ...
+        sv.set_option(capi.OPT_XSOLVE, capi.XSOLVE_REDUCED)             # ... only the cross-slab solve differs
+        sv.upload_layer(capi.LAYER_CUR, [f[x0:x1] for f in cur]); sv.upload_layer(capi.LAYER_TEMP, [f[x0:x1] for f in tmp])
+        sv.sweep(0, DT, capi.LAYER_CUR, capi.LAYER_TEMP, capi.LAYER_NEXT, merge=True)
+        ran = sv.last_sweep_kernels()["X"]
+        sw = sv.download_layer(capi.LAYER_NEXT), sv.download_layer(capi.LAYER_TEMP)
+        return ran, sw
+    res = grp.run(work)
+    assert all("reduced-interface" in r[0] for r in res)
+    tol = 5e-7 if dtype == np.float32 else 2e-15
+    for v in range(4):
+        nx = np.concatenate([res[r][1][0][v] for r in range(nranks)], axis=0)
+        tp = np.concatenate([res[r][1][1][v] for r in range(nranks)], axis=0)
+        assert rel(nx, ref_next[v]) <= tol and rel(tp, ref_temp[v]) <= tol, "sweep, field %d: %.2e / %.2e" % (v, rel(nx, ref_next[v]), rel(tp, ref_temp[v]))
+    grp.close()
+
+    grp = capi.LocalGroup(g, params, nranks, dtype)
+
+    def steps(r, sv):
+        sv.set_option(capi.OPT_SWEEP_KERNEL, capi.SWEEP_EXACT)
+        sv.set_option(capi.OPT_XSOLVE, capi.XSOLVE_REDUCED)
+        errs = []
+        for i in range(3):
+            sv.UpdateBoundaries(); errs.append(sv.TimeStep(DT, 4, 2, True))
+        return sv.download_layer(capi.LAYER_CUR), errs
+    res = grp.run(steps)
+    full = [np.concatenate([res[r][0][v] for r in range(nranks)], axis=0) for v in range(4)]
+    rv, rt = vec_rel(full, ref_cur), rel(full[3], ref_cur[3])
+    print("%d slabs, %s, 3 steps: velocity rel-L2 %.2e, T %.2e vs one context" % (nranks, np.dtype(dtype).name, rv, rt))
+    assert rv <= (TOL_STEPS if dtype == np.float32 else 1e-13) and rt <= (TOL_STEPS if dtype == np.float32 else 1e-13)
+    for r in range(nranks):
+        assert res[r][1][-1] == pytest.approx(ref_errs[-1], rel=1e-4 if dtype == np.float32 else 1e-10)
+    grp.close()
+
+
+def test_slabs_default_is_the_reduced_interface_solve(built):
+    """FS3D_SWEEP_AUTO on slabs: partition kernels for Y and Z, the reduced-interface X solve; against one context (AUTO)."""
+    g = grids.box(64, h=1.0 / 63)
+    params = capi.fluid_params(np.float32, *PARAMS)
+    s = capi.Solver(g, params, np.float32)
+    for i in range(2):
+        s.UpdateBoundaries(); s.TimeStep(DT, 4, 2, True)
+    ref = s.download_layer(capi.LAYER_CUR); s.close()
+    grp = capi.LocalGroup(g, params, 4, np.float32)
+
+    def steps(r, sv):
+        for i in range(2):
+            sv.UpdateBoundaries(); sv.TimeStep(DT, 4, 2, True)
+        return sv.download_layer(capi.LAYER_CUR), sv.last_sweep_kernels()
+    res = grp.run(steps)
+    assert res[0][1]["Y"] == "part" and res[0][1]["Z"] == "part" and "reduced-interface" in res[0][1]["X"]
+    full = [np.concatenate([res[r][0][v] for r in range(4)], axis=0) for v in range(4)]
+    assert vec_rel(full, ref) <= TOL_STEPS and rel(full[3], ref[3]) <= TOL_STEPS
+    grp.close()

@@ -81,3 +81,43 @@ def test_slab_ranges_cover_the_grid():
             assert all(rs[i][1] == rs[i + 1][0] for i in range(nr - 1))
             sizes = [b - a for a, b in rs]
             assert max(sizes) - min(sizes) <= 1
+
+
+# ---- reduced-interface form of the cross-slab X sweep (fs3d_hip.hip: xsweep_reduced) over gloo ----------------------
+def _worker_reduced(rank, world, port, n, nlines, dtype_name, out_dir):
+    """What every rank does: eliminate its own slab (k_xiface), ONE all-gather of the interface coefficients, the small
+    R x R solve per line (k_xreduce), back-substitution on its own slab with the two boundary values given."""
+    from cmc_fluid_solver_amd import partition as pt
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dtype = np.dtype(dtype_name)
+    a, b, c, d = _make_system(n, nlines, dtype, seed=11)
+    x0, x1 = slab.slab_range(n, rank, world)
+    sl = slice(x0, x1)
+    co = pt.chunk_eliminate(a[sl], b[sl], c[sl], d[sl])
+    keys = ["A", "Bp", "cl", "Dp", "Vf", "Wf", "Gf"]
+    mine = torch.from_numpy(np.stack([co[k] for k in keys]))                 # [7, nlines]: the slab's interface words
+    gathered = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine)                                          # the sweep's only exchange
+    cos = [{k: g[i].numpy() for i, k in enumerate(keys)} for g in gathered]
+    X = pt.thomas(*pt.reduced_rows(cos))                                     # every rank solves the R x R systems redundantly
+    x = pt.chunk_backsub(a[sl], b[sl], c[sl], d[sl], X[rank - 1] if rank else None, X[rank])
+    np.save(os.path.join(out_dir, "xr_%d.npy" % rank), x)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("dtype_name", ["float32", "float64"])
+def test_slab_reduced_interface_solve_equals_thomas(tmp_path, world, dtype_name):
+    from oracle import oracle as O
+    n, nlines = 41, 16
+    port = 29700 + world * 10 + (0 if dtype_name == "float32" else 1)
+    mp.spawn(_worker_reduced, args=(world, port, n, nlines, dtype_name, str(tmp_path)), nprocs=world, join=True)
+    x = np.concatenate([np.load(tmp_path / ("xr_%d.npy" % r)) for r in range(world)], axis=0)
+    a, b, c, d = _make_system(n, nlines, np.dtype(dtype_name), seed=11)
+    ref = np.stack([O.tridiag(a[:, l].astype(np.float64), b[:, l].astype(np.float64), c[:, l].astype(np.float64), d[:, l].astype(np.float64))
+                    for l in range(nlines)], axis=1)
+    err = np.linalg.norm(x - ref) / np.linalg.norm(ref)
+    assert err <= (1e-14 if dtype_name == "float64" else 5e-7), err
