@@ -67,11 +67,13 @@ static fs3d_status local_fail(fs3d_ctx *c, const char *what)
     return FS3D_ERR_COMM;
 }
 
+static hipStream_t xs(fs3d_ctx *c) { return c->xstream ? c->xstream : c->stream; }
+
 static fs3d_status local_exec(fs3d_ctx *c, const std::vector<XOp> &ops)
 {
     fs3d_local_group *g = (fs3d_local_group *)c->local;
     const int n = g->n, me = c->rank;
-    if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return local_fail(c, "stream sync before send");
+    if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(xs(c)) != hipSuccess) return local_fail(c, "stream sync before send");
     {
         std::lock_guard<std::mutex> lk(g->m);
         for (const XOp &o : ops) if (o.send) { g->box[(size_t)me * n + o.peer].push_back({o.ptr, o.count * c->esize}); g->posted[(size_t)me * n + o.peer]++; }
@@ -89,10 +91,10 @@ static fs3d_status local_exec(fs3d_ctx *c, const std::vector<XOp> &ops)
             msg = q.front(); q.pop_front();
         }
         if (msg.bytes != o.count * c->esize) return local_fail(c, "send/recv size mismatch");
-        if (hipMemcpyAsync(o.ptr, msg.ptr, msg.bytes, hipMemcpyDefault, c->stream) != hipSuccess) return local_fail(c, "device copy");
+        if (hipMemcpyAsync(o.ptr, msg.ptr, msg.bytes, hipMemcpyDefault, xs(c)) != hipSuccess) return local_fail(c, "device copy");
         took[o.peer]++;
     }
-    if (hipStreamSynchronize(c->stream) != hipSuccess) return local_fail(c, "stream sync after recv");
+    if (hipStreamSynchronize(xs(c)) != hipSuccess) return local_fail(c, "stream sync after recv");
     {
         std::unique_lock<std::mutex> lk(g->m);
         for (int p = 0; p < n; p++) g->done[(size_t)p * n + me] += took[p];
@@ -202,8 +204,8 @@ static fs3d_status exec_group(fs3d_ctx *c, const std::vector<XOp> &ops)
     const ncclDataType_t dt = c->prec == FS3D_F32 ? ncclFloat : ncclDouble;
     NCCLCHK(c, ncclGroupStart());
     for (const XOp &o : ops) {
-        const ncclResult_t r = o.send ? ncclSend(o.ptr, o.count, dt, o.peer, (ncclComm_t)c->comm, c->stream)
-                                      : ncclRecv(o.ptr, o.count, dt, o.peer, (ncclComm_t)c->comm, c->stream);
+        const ncclResult_t r = o.send ? ncclSend(o.ptr, o.count, dt, o.peer, (ncclComm_t)c->comm, xs(c))
+                                      : ncclRecv(o.ptr, o.count, dt, o.peer, (ncclComm_t)c->comm, xs(c));
         if (r != ncclSuccess) { ncclGroupEnd(); return cfail(c, o.send ? "ncclSend" : "ncclRecv", r); }     // never leave the group open
     }
     NCCLCHK(c, ncclGroupEnd());

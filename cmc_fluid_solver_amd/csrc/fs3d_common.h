@@ -60,6 +60,8 @@ struct SweepParams {
     long long carry_pitch;      // lines per value row of the carry arrays
     int fast_div;               // pipe kernel, fp32: constant divisors are in the range of the division core (kernels_pipe.hip)
     int merge;                  // 0: write next only; 1: also temp_out = merged; 2: merged twice (sweep merge + global merge)
+    int o_begin, o_count;       // partition kernels: only the planes [o_begin, o_begin + o_count) of the slab (Y and Z sweeps; o_count 0: all) --
+                                // interior planes run beside the halo exchange, the two edge planes after it
     int *errw;                  // device-visible error word (pinned host memory): bit 0 = a relay hand-over of the pipe kernel timed out
     int test_drop;              // test hook (env FS3D_TEST_DROP_HANDOFF): one wave never signals its hand-over; the poll bound is short
     int store_next;             // pipe kernel, fused time step: 0 when a later local iteration overwrites `next` unread (only the merge uses x)
@@ -95,6 +97,10 @@ struct fs3d_ctx {
     int red_blocks = 0;
     double diffError = 0.0;
     hipStream_t stream = nullptr;
+    hipStream_t comm_stream = nullptr;     // multi-GPU: halo planes travel here, beside the interior planes' sweep on `stream`
+    hipStream_t xstream = nullptr;         // the stream the transport works on right now (stream or comm_stream)
+    hipEvent_t ev_src = nullptr, ev_halo = nullptr;
+    int opt_overlap = 1;                   // FS3D_OPT_OVERLAP
     // options
     int opt_kernel = FS3D_SWEEP_AUTO;
     int ran_kernel[3] = {0, 0, 0};   // per direction: the kernel the last sweep really ran (fs3d_last_sweep_kernel)

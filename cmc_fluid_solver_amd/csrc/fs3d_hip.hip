@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "fs3d_common.h"
 #include "fs3d_comm.h"
@@ -267,6 +268,9 @@ extern "C" void fs3d_destroy(fs3d_ctx *c)
     if (c->red_host) hipHostFree(c->red_host);
     if (c->errw_host) hipHostFree(c->errw_host);
     for (auto e : c->ev) hipEventDestroy(e);
+    if (c->ev_src) hipEventDestroy(c->ev_src);
+    if (c->ev_halo) hipEventDestroy(c->ev_halo);
+    if (c->comm_stream) hipStreamDestroy(c->comm_stream);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -287,6 +291,7 @@ extern "C" fs3d_status fs3d_set_option(fs3d_ctx *c, int option, int value)
         c->opt_kernel = value; return FS3D_OK;
     case FS3D_OPT_FUSE_MERGE: c->opt_fuse = value ? 1 : 0; return FS3D_OK;
     case FS3D_OPT_DIV_CORE: c->opt_div_core = value ? 1 : 0; return FS3D_OK;
+    case FS3D_OPT_OVERLAP: c->opt_overlap = value ? 1 : 0; return FS3D_OK;
     case FS3D_OPT_XSOLVE:
         if (value < 0 || value > 2) return fail(c, FS3D_ERR_INVALID, "bad cross-slab X solve id");
         c->opt_xsolve = value; return FS3D_OK;
@@ -538,6 +543,7 @@ static void fill_params(fs3d_ctx *c, SweepParams<R> &p, int dir, double dt_, int
     p.store_next = (merge & 4) ? 0 : 1;      // merge | 4: the caller never reads this sweep's `next` (time_step_enqueue)
     p.stamps = nullptr;
     p.errw = c->errw_dev;
+    p.o_begin = 0; p.o_count = 0;
     { const char *e = getenv("FS3D_TEST_DROP_HANDOFF"); p.test_drop = (e && atoi(e)) ? 1 : 0; }
     p.carry_in = nullptr; p.carry_out = nullptr; p.xcarry_in = nullptr; p.xcarry_out = nullptr; p.bundle0 = 0;
     p.seg_begin = 0; p.seg_len = 0; p.carry_pitch = c->plane; p.seg_index = 0; p.scr_bundles = 0;
@@ -641,13 +647,63 @@ static fs3d_status xsweep_reduced(fs3d_ctx *c, SweepParams<R> &p)
     return FS3D_OK;
 }
 
-// one sweep on explicit buffers; merge: 0 none, 1 fused merge, 2 fused merge twice
+// Y / Z sweep of an x-slab with the halo planes of temp travelling BESIDE the sweep (north_star: "ghost-cell halo exchange ...
+// overlapped with interior-cell compute on a second HIP stream"; the reference exchanges first, TimeLayer3D.h:272-335 /
+// AdiSolver3D.cpp:608).  Only the first and the last owned plane read a ghost plane (the o+-1 neighbours of the stencils):
+//   stream        : interior planes [1, nx-1)  ........ wait(ev_halo) -> plane 0, plane nx-1
+//   comm_stream   : wait(ev_src) -> send / recv of the 4 x 2 halo planes -> ev_halo
+// ev_src marks the point where the planes to be sent are final (everything enqueued before this sweep).  Same kernels, same
+// cells, same values as the plain order -- only the launches are cut differently.  false: not applicable (caller exchanges
+// first and sweeps in one launch).
 template <typename R>
-static fs3d_status sweep_buffers(fs3d_ctx *c, int dir, double dt, int b_cur, int b_temp, int b_next, int b_tout, int merge)
+static bool sweep_overlapped(fs3d_ctx *c, int dir, SweepParams<R> &p, int b_temp, fs3d_status &st)
+{
+    st = FS3D_OK;
+    if (!c->opt_overlap || c->nranks < 2 || dir == 0 || c->dimx < 3) return false;
+    if (c->opt_kernel != FS3D_SWEEP_AUTO && c->opt_kernel != FS3D_SWEEP_PART) return false;
+    if (std::is_same<R, double>::value) return false;
+    if (!c->comm_stream) {
+        if (hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_src, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming) != hipSuccess) { st = fail(c, FS3D_ERR_HIP, "halo overlap: stream / event creation failed"); return true; }
+    }
+    if (hipEventRecord(c->ev_src, c->stream) != hipSuccess) { st = fail(c, FS3D_ERR_HIP, "halo overlap: event"); return true; }
+    p.o_begin = 1; p.o_count = c->dimx - 2;
+    if (!launch_sweep_part<R>(c, dir, p)) { p.o_begin = 0; p.o_count = 0; return false; }      // dims outside the partition kernels
+    c->ran_kernel[dir] = FS3D_SWEEP_PART; c->ran_segmented[dir] = 0;
+    // the interior planes are running; now the exchange, on its own stream, behind everything that was enqueued before them
+    if (hipStreamWaitEvent(c->comm_stream, c->ev_src, 0) != hipSuccess) { st = fail(c, FS3D_ERR_HIP, "halo overlap: event"); return true; }
+    c->xstream = c->comm_stream;
+    st = fs3d_comm_halo_exchange(c, b_temp, 4);
+    c->xstream = nullptr;
+    if (st) return true;
+    if (hipEventRecord(c->ev_halo, c->comm_stream) != hipSuccess || hipStreamWaitEvent(c->stream, c->ev_halo, 0) != hipSuccess) { st = fail(c, FS3D_ERR_HIP, "halo overlap: event"); return true; }
+    p.o_begin = 0; p.o_count = 1;
+    launch_sweep_part<R>(c, dir, p);
+    p.o_begin = c->dimx - 1; p.o_count = 1;
+    launch_sweep_part<R>(c, dir, p);
+    p.o_begin = 0; p.o_count = 0;
+    return true;
+}
+
+// one sweep on explicit buffers; merge: 0 none, 1 fused merge, 2 fused merge twice
+// halo: the temp layer's ghost planes are exchanged first -- or beside the interior planes (sweep_overlapped)
+template <typename R>
+static fs3d_status sweep_buffers(fs3d_ctx *c, int dir, double dt, int b_cur, int b_temp, int b_next, int b_tout, int merge, bool halo = false)
 {
     SweepParams<R> p;
     fill_params<R>(c, p, dir, dt, b_cur, b_temp, b_next, b_tout, merge);
     rec_begin(c, dir == 2 ? 0 : (dir == 1 ? 1 : 2));
+    if (halo) {
+        fs3d_status so;
+        if (sweep_overlapped<R>(c, dir, p, b_temp, so)) {
+            rec_end(c);
+            if (so) return so;
+            HIPCHK(c, hipGetLastError());
+            return FS3D_OK;
+        }
+        if ((so = fs3d_comm_halo_exchange(c, b_temp, 4))) { rec_end(c); return so; }
+    }
     if (dir == 0 && c->nranks > 1) {
         // reduced-interface form (all ranks at once) unless bit-equality with the sequential recurrence was asked for
         const bool reduced = c->opt_xsolve == 2 || (c->opt_xsolve == 0 && (c->opt_kernel == FS3D_SWEEP_AUTO || c->opt_kernel == FS3D_SWEEP_PART));
@@ -894,8 +950,7 @@ static fs3d_status time_step_enqueue(fs3d_ctx *c, double dt, int G, int L, bool 
                     // `next` of a local iteration that is not the last of its direction is overwritten by the following
                     // one without having been read (the merge into temp is fused into the kernel): not stored
                     const int merge = ((d == 2 && l == L - 1) ? 2 : 1) | (l < L - 1 ? 4 : 0);
-                    if ((st = fs3d_comm_halo_exchange(c, bTin, 4))) return st;
-                    if ((st = sweep_buffers<R>(c, plan[d][0], dt, plan[d][1], bTin, plan[d][2], bTout, merge))) return st;
+                    if ((st = sweep_buffers<R>(c, plan[d][0], dt, plan[d][1], bTin, plan[d][2], bTout, merge, true))) return st;
                     if (bTin == bCur) { bTin = bTout; bTout = bSpare; }
                     else { int t = bTin; bTin = bTout; bTout = t; }
                 }

@@ -162,7 +162,8 @@ __global__ void __launch_bounds__(LT * NCH, WPS) k_sweep_part(SweepParams<R> p, 
         const int wq = (t >> 6) * 4 / (LT * NCH / 64);
         if (wq == 1) __builtin_amdgcn_s_setprio(1); else if (wq == 2) __builtin_amdgcn_s_setprio(2); else if (wq == 3) __builtin_amdgcn_s_setprio(3);
     }      // timing experiments only (wrong numbers): FS3D_PART_ORDER bits 1, 2
-    const int tile_id = (order & 1) ? lb % n_tiles : lb / n_o, o = (order & 1) ? lb / n_tiles : lb - tile_id * n_o;
+    const int tile_id = (order & 1) ? lb % n_tiles : lb / n_o;
+    const int o = ((order & 1) ? lb / n_tiles : lb - tile_id * n_o) + (DIR == 1 ? p.o_begin : 0);
 
     const int n = DIR == 0 ? p.dimx : p.dimy;
     const int la_len = p.dimz;
@@ -491,7 +492,7 @@ __global__ void __launch_bounds__(LT * NCH, WPS) k_sweep_part(SweepParams<R> p, 
 template <typename R, int DIR, int M, int NCH, int WPS, int LT, int PF = FS3D_PART_PF>
 static bool part_launch_xy(fs3d_ctx *c, const SweepParams<R> &p)
 {
-    const int n_o = DIR == 0 ? p.dimy : p.dimx;
+    const int n_o = DIR == 0 ? p.dimy : (p.o_count ? p.o_count : p.dimx);
     const int n_tiles = (p.dimz + LT - 1) / LT;
     const size_t lds = ((size_t)NCH * M * LT + (size_t)(PART_EXW + (NCH > 16 ? 4 : 0)) * NCH * LT) * sizeof(R);
     static std::atomic<unsigned long long> attr_set{0};
@@ -523,7 +524,10 @@ static bool part_dispatch_xy(fs3d_ctx *c, const SweepParams<R> &p)
             if (variant == 4) return part_launch_xy<R, DIR, 16, 16, 4, 32, 1>(c, p);
             if (variant == 5) return part_launch_xy<R, DIR, 16, 16, 4, 32, 3>(c, p);
             if (variant == 6) return part_launch_xy<R, DIR, 32, 8, 2, 32, 4>(c, p);
-            if (variant == 7) return part_launch_xy<R, DIR, 16, 16, 4, 32>(c, p);    // 32 lines, two workgroups per CU
+            // thin slabs (a 32-plane x-slab of the 256^3 box: 32 x 4 workgroups of 64 lines for 256 CUs): 32-line
+            // workgroups, twice as many
+            const int n_o = DIR == 0 ? p.dimy : p.dimx;
+            if (variant == 7 || (long long)n_o * ((p.dimz + 63) / 64) < 256) return part_launch_xy<R, DIR, 16, 16, 4, 32>(c, p);
             // 64 lines x 16 chunks: 256-byte row pieces (measured: 1.1x the speed of 128-byte pieces in the Y sweep, 1.2x in X)
             return part_launch_xy<R, DIR, 16, 16, 4, 64>(c, p);
         }
@@ -579,7 +583,8 @@ __global__ void __launch_bounds__(256, WPS) k_sweep_part_z(SweepParams<float> p,
     }
     // task = (group of LG*LI lines, plane): consecutive tasks = consecutive planes of one line group
     const int task = lb * 4 + w;
-    const int grp = task / p.dimx, i = task - grp * p.dimx;
+    const int npl = p.o_count ? p.o_count : p.dimx;    // planes of this launch
+    const int grp = task / npl, i = task - grp * npl + p.o_begin;
     if (grp >= n_grp) return;                           // whole wave (wave-uniform)
     const int n = p.dimz;
     const int j0 = grp * LG * LI;
@@ -861,7 +866,7 @@ static bool part_launch_z(fs3d_ctx *c, const SweepParams<float> &p)
     const int rows = (p.dimy + LI - 1) / LI;              // rows of LI lines per plane
     if (LG > rows) LG = rows;
     const int n_grp = (rows + LG - 1) / LG;
-    const long long tasks = (long long)n_grp * p.dimx;
+    const long long tasks = (long long)n_grp * (p.o_count ? p.o_count : p.dimx);
     static const int wps = getenv("FS3D_PART_ZWPS") ? atoi(getenv("FS3D_PART_ZWPS")) : 2;     // kernel experiments
     if (wps == 3) hipLaunchKernelGGL((k_sweep_part_z<LPL, 3>), dim3((unsigned)((tasks + 3) / 4)), dim3(256), 0, c->stream, p, n_grp, LG);
     else hipLaunchKernelGGL((k_sweep_part_z<LPL, 2>), dim3((unsigned)((tasks + 3) / 4)), dim3(256), 0, c->stream, p, n_grp, LG);

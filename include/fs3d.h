@@ -62,6 +62,8 @@ enum {
 enum {
     FS3D_OPT_SWEEP_KERNEL = 0,
     FS3D_OPT_FUSE_MERGE = 1,  /* 1 (default): merge fused into the sweep; 0: separate merge kernels */
+    FS3D_OPT_OVERLAP = 4,     /* 1 (default): in a multi-GPU group the halo planes of a Y / Z sweep travel on a second stream beside the
+                                 sweep of the interior planes, the two edge planes follow; 0: exchange first, then one launch */
     FS3D_OPT_XSOLVE = 3,      /* cross-slab X sweep of a multi-GPU group: 1 = pipelined over the ranks (the reference's form,
                                  AdiSolver3D.cu:524-640; bit-equal to one GPU), 2 = reduced interface (every rank eliminates its slab
                                  at once, one all-gather per sweep; equal to one GPU to rounding), 0 (default) = 2 unless the

@@ -439,3 +439,28 @@ def test_slabs_default_is_the_reduced_interface_solve(built):
     full = [np.concatenate([res[r][0][v] for r in range(4)], axis=0) for v in range(4)]
     assert vec_rel(full, ref) <= TOL_STEPS and rel(full[3], ref[3]) <= TOL_STEPS
     grp.close()
+
+
+@pytest.mark.parametrize("nranks", [2, 4])
+def test_halo_planes_beside_the_interior_sweep(built, nranks):
+    """FS3D_OPT_OVERLAP: interior planes of a slab's Y / Z sweep run beside the halo exchange (second stream), the two edge
+    planes after it.  Same kernels on the same cells: the fields equal the exchange-first order bit for bit; three steps."""
+    g = grids.box_with_obstacle(64, 40, 64, h=0.02)
+    params = capi.fluid_params(np.float32, *PARAMS)
+    out = {}
+    for overlap in (1, 0):
+        grp = capi.LocalGroup(g, params, nranks, np.float32)
+
+        def steps(r, sv):
+            sv.set_option(capi.OPT_OVERLAP, overlap)
+            errs = []
+            for i in range(3):
+                sv.UpdateBoundaries(); errs.append(sv.TimeStep(DT, 4, 2, True))
+            return sv.download_layer(capi.LAYER_CUR), errs, sv.last_sweep_kernels()
+        res = grp.run(steps)
+        assert res[0][2]["Y"] == "part" and res[0][2]["Z"] == "part"
+        out[overlap] = [np.concatenate([res[r][0][v] for r in range(nranks)], axis=0) for v in range(4)], res[0][1]
+        grp.close()
+    for a, b in zip(out[1][0], out[0][0]):
+        assert np.array_equal(a, b)
+    assert out[1][1] == out[0][1]
