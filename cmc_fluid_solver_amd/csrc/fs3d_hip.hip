@@ -633,10 +633,17 @@ static fs3d_status xsweep_reduced(fs3d_ctx *c, SweepParams<R> &p)
     launch_xiface<R>(c, p, c->xif_send);
     if ((st = fs3d_comm_allgather(c, c->xif_send, c->xif_all, 18 * pl))) return st;
     launch_xreduce<R>(c, c->xif_all, (long long)pl, c->nranks, c->rank, c->carry[0], c->carry[2]);
-    const bool pipe = c->opt_kernel != FS3D_SWEEP_LINE && xslab_pipe_supported<R>(p);
-    c->ran_kernel[0] = pipe ? FS3D_SWEEP_PIPE : FS3D_SWEEP_LINE; c->ran_segmented[0] = 1; c->ran_xsolve = 2;
     p.carry_in = (const R *)c->carry[0]; p.carry_out = (R *)c->carry[1];
     p.xcarry_in = (const R *)c->carry[2]; p.xcarry_out = (R *)c->carry[3];
+    c->ran_xsolve = 2;
+    // the slab with both boundary values given: the X partition kernel (rows on chip, 16 words per cell) where it applies ...
+    if ((c->opt_kernel == FS3D_SWEEP_AUTO || c->opt_kernel == FS3D_SWEEP_PART) && launch_sweep_part<R>(c, 0, p)) {
+        c->ran_kernel[0] = FS3D_SWEEP_PART; c->ran_segmented[0] = 0;
+        return FS3D_OK;
+    }
+    // ... else the exact halves (rows through the HBM scratch)
+    const bool pipe = c->opt_kernel != FS3D_SWEEP_LINE && xslab_pipe_supported<R>(p);
+    c->ran_kernel[0] = pipe ? FS3D_SWEEP_PIPE : FS3D_SWEEP_LINE; c->ran_segmented[0] = 1;
     if (pipe) {
         if (!launch_xslab_pipe<R>(c, p, 1, 0, (int)(pl / 64))) return st = fail(c, FS3D_ERR_HIP, "pipe kernel launch (forward half)");
         if (!launch_xslab_pipe<R>(c, p, 2, 0, (int)(pl / 64))) return st = fail(c, FS3D_ERR_HIP, "pipe kernel launch (backward half)");

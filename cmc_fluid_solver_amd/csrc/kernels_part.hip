@@ -134,7 +134,7 @@ __device__ __forceinline__ void part_step(R lead, R diag, R trail, R &cp, R &sp,
 #endif
 #define PART_EXW 18               // interface words per (line, chunk): 5 per matrix, 2 per right-hand side
 
-template <typename R, int DIR, int M, int NCH, int WPS, int LT, int PF = FS3D_PART_PF>
+template <typename R, int DIR, int M, int NCH, int WPS, int LT, int PF = FS3D_PART_PF, bool XB = false>
 __global__ void __launch_bounds__(LT * NCH, WPS) k_sweep_part(SweepParams<R> p, int n_o, int n_tiles, int order)
 {
     static_assert(DIR == 0 || DIR == 1, "lanes along k: X and Y sweeps");
@@ -260,6 +260,14 @@ __global__ void __launch_bounds__(LT * NCH, WPS) k_sweep_part(SweepParams<R> p, 
     // They must not keep the other lines of the wave off the select-free paths: they run along as INTERIOR rows --
     // finite or not, whatever they produce stays in its lane (and in its own interface system).
     const bool dead = p.dead[(long long)o * p.dimz + kc] != 0;
+    // X sweep of an x-slab (reduced-interface form, fs3d_hip.hip: xsweep_reduced): the values just below / above the slab on
+    // this line are given -- x[-1] in p.carry_in rows 2..5, x[n] in p.xcarry_in rows 0..3 ([value][line], line = j*dimz + k)
+    constexpr bool xb = XB && DIR == 0;                  // a template parameter: the single-GPU instance must not pay registers for it
+    // this lane's line in the carry arrays, recomputed where it is needed (a register kept across the kernel costs spills)
+    auto cline_of = [&]() __attribute__((always_inline)) {
+        const unsigned kc_ = opq_v(vo) / (unsigned)sizeof(R) - (unsigned)((long long)(opq_v(t) / LT * M) * ss);
+        return (long long)o * p.dimz + kc_;
+    };
     // cells that are INTERIOR rows on all 64 lanes of the wave: plain scalar branches pick the select-free code
     unsigned umask;
     {
@@ -311,6 +319,12 @@ __global__ void __launch_bounds__(LT * NCH, WPS) k_sweep_part(SweepParams<R> p, 
 #pragma unroll
                 for (int f = 0; f < 3; f++) dd[f] = is_int ? dd[f] : (ns_v ? nv[f] : R(0));
                 dd[3] = is_int ? dd[3] : (ns_t ? nv[3] : R(0));
+                if (xb && __any(s0 + i == n)) {
+                    // the first cell past the slab: an identity row that holds the given x[n] (the last plane's rows couple to it)
+                    const long long cline = cline_of();
+#pragma unroll
+                    for (int f = 0; f < 4; f++) { const R xr = p.xcarry_in[(long long)f * p.carry_pitch + cline]; dd[f] = s0 + i == n ? xr : dd[f]; }
+                }
             }
             q[i] = qq; dU[i] = dd[0]; dV[i] = dd[1]; dW[i] = dd[2];
             ldsD[(s0 + i) * LT + kk] = dd[3];
@@ -373,11 +387,19 @@ __global__ void __launch_bounds__(LT * NCH, WPS) k_sweep_part(SweepParams<R> p, 
         constexpr bool RL = NCH > 16;
         R cpa[RL ? 1 : NCH], dpa[RL ? 1 : NCH];
         R *const cx = ex + PART_EXW * ES + sys * ES + kk;
-        R cp = R(0), dp = R(0);
+        // slab mode: the row of chunk 0 couples to the given x[-1] (lo * x[-1] moves to the right-hand side: start the
+        // recurrence from d' = x[-1], c' = 0); a line that fills all chunks couples its last row to the given x[n]
+        R cp = R(0), dp = R(0), xr_last = R(0);
+        if (xb) {
+            const long long cline = cline_of();
+            dp = p.carry_in[(long long)(2 + sys) * p.carry_pitch + cline];
+            if (n == NCH * M) xr_last = p.xcarry_in[(long long)sys * p.carry_pitch + cline];
+        }
         auto fwd = [&](int c) __attribute__((always_inline)) {
             const R lo = em[0 * ES + c * LT], bp = em[1 * ES + c * LT], cl = em[2 * ES + c * LT];
             R vf = R(0), wf = R(0), gf = R(0);
             if (c + 1 < NCH) { vf = em[3 * ES + (c + 1) * LT]; wf = em[4 * ES + (c + 1) * LT]; gf = er[4 * ES + (c + 1) * LT]; }
+            else gf = xr_last;
             const R di = pfma(-cl, vf, bp), up = -cl * wf, rhs = pfma(-cl, gf, er[c * LT]);
             const R den = pfma(-lo, cp, di), r = prcp(den);
             cp = pquot(up, den, r); dp = pquot(pfma(-lo, dp, rhs), den, r);
@@ -411,6 +433,13 @@ __global__ void __launch_bounds__(LT * NCH, WPS) k_sweep_part(SweepParams<R> p, 
 #pragma unroll
         for (int s = 0; s < 3; s++) dp3[s] = ch > 0 ? ex[(10 + s) * ES + (ch - 1) * LT + kk] : R(0);
         dp1[0] = ch > 0 ? ex[13 * ES + (ch - 1) * LT + kk] : R(0);
+        if (xb && __any(ch == 0)) {                      // chunk 0 of a slab: the given x[-1]
+            const long long cline = cline_of();
+#pragma unroll
+            for (int s = 0; s < 3; s++) { const R xl = p.carry_in[(long long)(2 + s) * p.carry_pitch + cline]; dp3[s] = ch == 0 ? xl : dp3[s]; }
+            const R xl = p.carry_in[5ll * p.carry_pitch + cline];
+            dp1[0] = ch == 0 ? xl : dp1[0];
+        }
         R cpv = R(0), cpt = R(0), sp = R(0);
         R tdn = myD[0];
         pstatic_for<M - 1>([&](auto ic) __attribute__((always_inline)) {
@@ -489,7 +518,7 @@ __global__ void __launch_bounds__(LT * NCH, WPS) k_sweep_part(SweepParams<R> p, 
 #undef PSTAMP
 }
 
-template <typename R, int DIR, int M, int NCH, int WPS, int LT, int PF = FS3D_PART_PF>
+template <typename R, int DIR, int M, int NCH, int WPS, int LT, int PF = FS3D_PART_PF, bool XB = false>
 static bool part_launch_xy(fs3d_ctx *c, const SweepParams<R> &p)
 {
     const int n_o = DIR == 0 ? p.dimy : (p.o_count ? p.o_count : p.dimx);
@@ -498,14 +527,14 @@ static bool part_launch_xy(fs3d_ctx *c, const SweepParams<R> &p)
     static std::atomic<unsigned long long> attr_set{0};
     const unsigned long long dev_bit = 1ull << (c->device & 63);
     if (!(attr_set.load() & dev_bit)) {
-        if (hipFuncSetAttribute((const void *)k_sweep_part<R, DIR, M, NCH, WPS, LT, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        if (hipFuncSetAttribute((const void *)k_sweep_part<R, DIR, M, NCH, WPS, LT, PF, XB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             c->err = std::string("partition kernel: hipFuncSetAttribute: ") + hipGetErrorString(hipGetLastError());
             return false;
         }
         attr_set.fetch_or(dev_bit);
     }
     static const int order = getenv("FS3D_PART_ORDER") ? atoi(getenv("FS3D_PART_ORDER")) : 0;   // kernel experiments
-    hipLaunchKernelGGL((k_sweep_part<R, DIR, M, NCH, WPS, LT, PF>), dim3((unsigned)(n_o * n_tiles)), dim3(LT * NCH), lds, c->stream, p, n_o, n_tiles, order);
+    hipLaunchKernelGGL((k_sweep_part<R, DIR, M, NCH, WPS, LT, PF, XB>), dim3((unsigned)(n_o * n_tiles)), dim3(LT * NCH), lds, c->stream, p, n_o, n_tiles, order);
     return true;
 }
 
@@ -514,8 +543,16 @@ static bool part_dispatch_xy(fs3d_ctx *c, const SweepParams<R> &p)
 {
     const int n = DIR == 0 ? p.dimx : p.dimy;
     if (n < 4) return false;
-    if (std::is_same<R, float>::value) {
+    if constexpr (std::is_same<R, float>::value) {       // fp64 contexts run the exact kernels
         static const int variant = getenv("FS3D_PART_VARIANT") ? atoi(getenv("FS3D_PART_VARIANT")) : 0;   // kernel experiments
+        if (DIR == 0 && p.carry_in && p.xcarry_in) {
+            // x-slab with the values below / above it given (reduced-interface form of the cross-slab sweep)
+            constexpr int D0 = 0;
+            if (n <= 64) return part_launch_xy<R, D0, 16, 4, 4, 32, FS3D_PART_PF, true>(c, p);
+            if (n <= 128) return part_launch_xy<R, D0, 16, 8, 4, 32, FS3D_PART_PF, true>(c, p);
+            if (n <= 256) return part_launch_xy<R, D0, 16, 16, 4, 64, FS3D_PART_PF, true>(c, p);
+            return false;
+        }
         if (n <= 64) return part_launch_xy<R, DIR, 16, 4, 4, 32>(c, p);
         if (n <= 128) return part_launch_xy<R, DIR, 16, 8, 4, 32>(c, p);
         if (n <= 256) {
@@ -867,9 +904,8 @@ static bool part_launch_z(fs3d_ctx *c, const SweepParams<float> &p)
     if (LG > rows) LG = rows;
     const int n_grp = (rows + LG - 1) / LG;
     const long long tasks = (long long)n_grp * (p.o_count ? p.o_count : p.dimx);
-    static const int wps = getenv("FS3D_PART_ZWPS") ? atoi(getenv("FS3D_PART_ZWPS")) : 2;     // kernel experiments
-    if (wps == 3) hipLaunchKernelGGL((k_sweep_part_z<LPL, 3>), dim3((unsigned)((tasks + 3) / 4)), dim3(256), 0, c->stream, p, n_grp, LG);
-    else hipLaunchKernelGGL((k_sweep_part_z<LPL, 2>), dim3((unsigned)((tasks + 3) / 4)), dim3(256), 0, c->stream, p, n_grp, LG);
+    // 2 waves per SIMD: the kernel needs ~200 VGPRs (at 168 it spills 70 of them and runs 1.5x slower)
+    hipLaunchKernelGGL((k_sweep_part_z<LPL, 2>), dim3((unsigned)((tasks + 3) / 4)), dim3(256), 0, c->stream, p, n_grp, LG);
     return true;
 }
 
@@ -890,7 +926,7 @@ template <typename R>
 bool launch_sweep_part(fs3d_ctx *c, int dir, const SweepParams<R> &p)
 {
     if ((unsigned long long)p.fstride * 4ull * sizeof(R) >= (1ull << 32)) return false;   // 32-bit buffer offsets span a layer
-    if (dir == 0 && (p.ghost_lo || p.ghost_hi)) return false;                            // X sweep of an x-slab: own path
+    if (dir == 0 && (p.ghost_lo || p.ghost_hi) && !(p.carry_in && p.xcarry_in)) return false;   // X sweep of an x-slab: only with the values below / above the slab given
     if (dir == 0) return part_dispatch_xy<R, 0>(c, p);
     if (dir == 1) return part_dispatch_xy<R, 1>(c, p);
     return part_dispatch_z(c, p);

@@ -1,14 +1,24 @@
-set -o pipefail
-python -m pytest tests -q -m gpu 2>&1 | tail -5 > gpurun_out/gpu_tests.log; cat gpurun_out/gpu_tests.log
-cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r2_stats -o r2 -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/r2_stats.log 2>&1
-for grp in "FETCH_SIZE" "WRITE_SIZE"; do
-  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$grp -o p -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_$grp.log 2>&1
-done
-cd $R
-find gpurun_out/r2_stats -name "*kernel_stats.csv" | head -2
-cp $(find gpurun_out/r2_stats -name "*kernel_stats.csv" | head -1) gpurun_out/r2_bench_kernel_stats.csv
-python tools/pmc_traffic.py $(find gpurun_out/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1) $(find gpurun_out/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1) > gpurun_out/r2_pmc_traffic.txt
-rm -rf gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE gpurun_out/r2_stats
-head -20 gpurun_out/r2_bench_kernel_stats.csv; cat gpurun_out/r2_pmc_traffic.txt
+python -m pytest tests/test_gpu_part.py tests/test_gpu_slabs.py tests/test_gpu_failures.py -q -m gpu 2>&1 | tail -4
+python - <<'PY'
+import sys; sys.path.insert(0,'tools'); sys.argv=['x']
+import numpy as np, time
+import part_check as pc
+from cmc_fluid_solver_amd import capi, grids
+pc.timing(256, capi.SWEEP_AUTO)
+# a 256^3 box as 8 slabs on one card: time per step of one slab thread (all 8 share the card: ~sum of the slabs' work)
+g = grids.box(256, h=1.0/255)
+params = capi.fluid_params(np.float32, 200.0, 0.72, 1.4)
+for xs in (capi.XSOLVE_REDUCED, capi.XSOLVE_PIPELINED):
+    grp = capi.LocalGroup(g, params, 8, np.float32)
+    def work(r, sv):
+        sv.set_option(capi.OPT_XSOLVE, xs)
+        for i in range(2):
+            sv.UpdateBoundaries(); sv.TimeStep(0.1, 4, 2, False)
+        t0 = time.perf_counter()
+        for i in range(5):
+            sv.UpdateBoundaries(); sv.TimeStep(0.1, 4, 2, False)
+        return (time.perf_counter() - t0) / 5, sv.last_sweep_kernels()
+    res = grp.run(work)
+    print("8 slabs of the 256^3 box on ONE card, xsolve %d: %.2f ms per step (all slabs share the card), ran %s" % (xs, max(r[0] for r in res) * 1e3, res[0][1]))
+    grp.close()
+PY
