@@ -132,9 +132,12 @@ __device__ __forceinline__ void part_step(R lead, R diag, R trail, R &cp, R &sp,
 #ifndef FS3D_PART_PF
 #define FS3D_PART_PF 2            // cells whose loads are in flight ahead of the cell being computed (P phase)
 #endif
+#ifndef FS3D_PART_OPF
+#define FS3D_PART_OPF 2           // cells whose temp values are in flight ahead of the cell being stored (O phase)
+#endif
 #define PART_EXW 18               // interface words per (line, chunk): 5 per matrix, 2 per right-hand side
 
-template <typename R, int DIR, int M, int NCH, int WPS, int LT, int PF = FS3D_PART_PF, bool XB = false>
+template <typename R, int DIR, int M, int NCH, int WPS, int LT, int PF = FS3D_PART_PF, bool XB = false, int OPF = FS3D_PART_OPF, bool KT = false>
 __global__ void __launch_bounds__(LT * NCH, WPS) k_sweep_part(SweepParams<R> p, int n_o, int n_tiles, int order)
 {
     static_assert(DIR == 0 || DIR == 1, "lanes along k: X and Y sweeps");
@@ -282,6 +285,7 @@ __global__ void __launch_bounds__(LT * NCH, WPS) k_sweep_part(SweepParams<R> p, 
     PSTAMP(1);
     // ---- P: rows -------------------------------------------------------------------------------------------
     R q[M], dU[M], dV[M], dW[M];
+    R tkeep[KT ? 4 : 1][KT ? M : 1];                     // KT: the temp values of the own cells stay in registers for the merge (no second read)
     {
         pstatic_for<M>([&](auto ic) __attribute__((always_inline)) {
             constexpr int i = decltype(ic)::value;
@@ -327,6 +331,10 @@ __global__ void __launch_bounds__(LT * NCH, WPS) k_sweep_part(SweepParams<R> p, 
                 }
             }
             q[i] = qq; dU[i] = dd[0]; dV[i] = dd[1]; dW[i] = dd[2];
+            if (KT) {
+#pragma unroll
+                for (int f = 0; f < 4; f++) tkeep[f][i] = Tc[f];
+            }
             ldsD[(s0 + i) * LT + kk] = dd[3];
 #pragma unroll
             for (int f = 0; f < 4; f++) { Tm[f] = Tc[f]; Tc[f] = c.tp[f]; }
@@ -466,7 +474,6 @@ __global__ void __launch_bounds__(LT * NCH, WPS) k_sweep_part(SweepParams<R> p, 
     {
         const unsigned vo_st = lane_valid ? vo : PART_OOB;
         const unsigned so0 = opq_s(so0_p), ssb = opq_s(ssb_p), fsb = opq_s(fsb_p);   // not the P phase's address arithmetic kept alive
-        constexpr int OPF = 2;                          // cells whose temp values are in flight ahead
         R tv[OPF + 1][4];
         unsigned s_is = so0, s_o = so0;                 // running scalar offsets (issue side / store side), opaque per cell
         const unsigned segm = opq_v(segmask), inm = opq_v(inmask);
@@ -476,7 +483,7 @@ __global__ void __launch_bounds__(LT * NCH, WPS) k_sweep_part(SweepParams<R> p, 
             for (int f = 0; f < 4; f++) v[f] = x_nore ? R(f) : PBuf<R>::ld(Ltmp, vo, s_is + (unsigned)f * fsb);
             s_is = opq_s(s_is + ssb);
         };
-        if (p.merge) {
+        if (p.merge && !KT) {
 #pragma unroll
             for (int i = 0; i < OPF && i < M; i++) issue(tv[i]);
         }
@@ -484,7 +491,7 @@ __global__ void __launch_bounds__(LT * NCH, WPS) k_sweep_part(SweepParams<R> p, 
             constexpr int i = decltype(ic)::value;
             const unsigned sc = s_o;
             s_o = opq_s(s_o + ssb);
-            if (p.merge && i + OPF < M) issue(tv[(i + OPF) % (OPF + 1)]);
+            if (p.merge && !KT && i + OPF < M) issue(tv[(i + OPF) % (OPF + 1)]);
             __builtin_amdgcn_sched_barrier(0);
             R xv[4] = {dU[i], dV[i], dW[i], dT[i]};
             const bool uni = (opq_s(umask) >> i) & 1u;
@@ -496,7 +503,9 @@ __global__ void __launch_bounds__(LT * NCH, WPS) k_sweep_part(SweepParams<R> p, 
                 for (int f = 0; f < 4; f++) PBuf<R>::st(Lnext, v_, sc + (unsigned)f * fsb, xv[f]);
             }
             if (p.merge) {
-                R (&tq)[4] = tv[i % (OPF + 1)];
+                R tq[4];
+#pragma unroll
+                for (int f = 0; f < 4; f++) tq[f] = KT ? tkeep[f][KT ? i : 0] : tv[i % (OPF + 1)][f];
                 if (!uni && __any(isin && !seg)) {
                     // NODE_IN cell outside every segment (run without a closing cell, Grid3D.cpp:87-117): the reference
                     // merges the stale `next` value
@@ -518,7 +527,7 @@ __global__ void __launch_bounds__(LT * NCH, WPS) k_sweep_part(SweepParams<R> p, 
 #undef PSTAMP
 }
 
-template <typename R, int DIR, int M, int NCH, int WPS, int LT, int PF = FS3D_PART_PF, bool XB = false>
+template <typename R, int DIR, int M, int NCH, int WPS, int LT, int PF = FS3D_PART_PF, bool XB = false, int OPF = FS3D_PART_OPF, bool KT = false>
 static bool part_launch_xy(fs3d_ctx *c, const SweepParams<R> &p)
 {
     const int n_o = DIR == 0 ? p.dimy : (p.o_count ? p.o_count : p.dimx);
@@ -527,14 +536,14 @@ static bool part_launch_xy(fs3d_ctx *c, const SweepParams<R> &p)
     static std::atomic<unsigned long long> attr_set{0};
     const unsigned long long dev_bit = 1ull << (c->device & 63);
     if (!(attr_set.load() & dev_bit)) {
-        if (hipFuncSetAttribute((const void *)k_sweep_part<R, DIR, M, NCH, WPS, LT, PF, XB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        if (hipFuncSetAttribute((const void *)k_sweep_part<R, DIR, M, NCH, WPS, LT, PF, XB, OPF, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             c->err = std::string("partition kernel: hipFuncSetAttribute: ") + hipGetErrorString(hipGetLastError());
             return false;
         }
         attr_set.fetch_or(dev_bit);
     }
     static const int order = getenv("FS3D_PART_ORDER") ? atoi(getenv("FS3D_PART_ORDER")) : 0;   // kernel experiments
-    hipLaunchKernelGGL((k_sweep_part<R, DIR, M, NCH, WPS, LT, PF, XB>), dim3((unsigned)(n_o * n_tiles)), dim3(LT * NCH), lds, c->stream, p, n_o, n_tiles, order);
+    hipLaunchKernelGGL((k_sweep_part<R, DIR, M, NCH, WPS, LT, PF, XB, OPF, KT>), dim3((unsigned)(n_o * n_tiles)), dim3(LT * NCH), lds, c->stream, p, n_o, n_tiles, order);
     return true;
 }
 
@@ -556,11 +565,11 @@ static bool part_dispatch_xy(fs3d_ctx *c, const SweepParams<R> &p)
         if (n <= 64) return part_launch_xy<R, DIR, 16, 4, 4, 32>(c, p);
         if (n <= 128) return part_launch_xy<R, DIR, 16, 8, 4, 32>(c, p);
         if (n <= 256) {
-            if (variant == 1) return part_launch_xy<R, DIR, 32, 8, 2, 32>(c, p);     // 256 threads x 32 cells, <= 256 VGPRs
-            if (variant == 3) return part_launch_xy<R, DIR, 32, 8, 2, 64>(c, p);     // 64 lines x 32 cells, 512 threads, one per CU
-            if (variant == 4) return part_launch_xy<R, DIR, 16, 16, 4, 32, 1>(c, p);
-            if (variant == 5) return part_launch_xy<R, DIR, 16, 16, 4, 32, 3>(c, p);
-            if (variant == 6) return part_launch_xy<R, DIR, 32, 8, 2, 32, 4>(c, p);
+            // measured alternatives (profiles/r2_variants.txt), kept for re-measurement on other boxes:
+            if (variant == 1) return part_launch_xy<R, DIR, 32, 8, 2, 32>(c, p);     // 256 threads x 32 cells, <= 256 VGPRs: 1.15x slower
+            if (variant == 10) return part_launch_xy<R, DIR, 8, 32, 4, 32, 2, false, 2, true>(c, p);   // 8 cells per thread, 32 lines, the temp values
+                                                                                                    // stay in registers for the merge: 1.1x slower
+                                                                                                    // (without keeping them: 1.25x)
             // thin slabs (a 32-plane x-slab of the 256^3 box: 32 x 4 workgroups of 64 lines for 256 CUs): 32-line
             // workgroups, twice as many
             const int n_o = DIR == 0 ? p.dimy : p.dimx;

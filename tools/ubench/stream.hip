@@ -23,7 +23,7 @@ __global__ void __launch_bounds__(256) k_copy4(const float4 *__restrict__ in, fl
 }
 
 // dir 0: X-like (sweep stride = plane, o stride = dimz); dir 1: Y-like (sweep stride = dimz, o stride = plane)
-template <int LT, int M, int NCH, int NFI, int NFO, int WPS>
+template <int LT, int M, int NCH, int NFI, int NFO, int WPS, int NRR = 0, int NNB = 0>
 __global__ void __launch_bounds__(LT * NCH, WPS) k_sheet(const float *__restrict__ in, float *__restrict__ out, int dim, int dir, size_t fstride, int n_o, int n_tiles, int order)
 {
     int lb = blockIdx.x;
@@ -50,21 +50,28 @@ __global__ void __launch_bounds__(LT * NCH, WPS) k_sheet(const float *__restrict
 #pragma unroll
             for (int f = 0; f < NFI; f++) v[(i + PF) % (PF + 1)][f] = in[f * fstride + base + (i + PF) * ss];
         }
+        // NNB: the rows of the neighbouring workgroups (o +- 1) of field 0, as the stencils of the real kernels read them
+        float nb = 0.f;
+        if (NNB) { nb = in[base + i * ss + os] + in[base + i * ss - os]; }
         __builtin_amdgcn_sched_barrier(0);
         float s = 0.f;
 #pragma unroll
         for (int f = 0; f < NFI; f++) s += v[i % (PF + 1)][f];
 #pragma unroll
         for (int f = 0; f < NFO; f++) res[i][f] = s + (float)f;
-        keep += s;
+        keep += s + nb;
         __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
     if (NFO == 0 && keep == 12345.678f) out[base] = keep;      // loads-only variant: keep the loads alive
 #pragma unroll
     for (int i = 0; i < M; i++) {
+        // NRR: fields read a second time by the store phase (the merge's temp values in the real kernels)
+        float rr = 0.f;
 #pragma unroll
-        for (int f = 0; f < NFO; f++) out[f * fstride + base + i * ss] = res[i][f];
+        for (int f = 0; f < NRR; f++) rr += in[(4 + f) * fstride + base + i * ss];
+#pragma unroll
+        for (int f = 0; f < NFO; f++) out[f * fstride + base + i * ss] = res[i][f] + rr;
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -82,7 +89,7 @@ static float time_ms(hipStream_t st, int reps, void (*fn)(void *), void *ctx)
 
 struct Ctx { const float *in; float *out; int dim; size_t fstride; hipStream_t st; int dir, order; };
 
-template <int LT, int M, int NCH, int NFI, int NFO, int WPS>
+template <int LT, int M, int NCH, int NFI, int NFO, int WPS, int NRR = 0, int NNB = 0>
 static void run_sheet(Ctx &c, const char *name)
 {
     for (int dir = 0; dir < 2; dir++) for (int order = 0; order < 2; order++) {
@@ -90,7 +97,7 @@ static void run_sheet(Ctx &c, const char *name)
         auto fn = [](void *p) {
             Ctx &c = *(Ctx *)p;
             const int n_o = c.dim, n_tiles = c.dim / LT;
-            hipLaunchKernelGGL((k_sheet<LT, M, NCH, NFI, NFO, WPS>), dim3(n_o * n_tiles), dim3(LT * NCH), 0, c.st, c.in, c.out, c.dim, c.dir, c.fstride, n_o, n_tiles, c.order);
+            hipLaunchKernelGGL((k_sheet<LT, M, NCH, NFI, NFO, WPS, NRR, NNB>), dim3(n_o * n_tiles), dim3(LT * NCH), 0, c.st, c.in, c.out, c.dim, c.dir, c.fstride, n_o, n_tiles, c.order);
         };
         const float ms = time_ms(c.st, 10, fn, &c);
         const double bytes = (double)c.dim * c.dim * c.dim * 4.0 * (NFI + NFO);
@@ -117,6 +124,8 @@ int main()
     }
     run_sheet<32, 16, 16, 8, 8, 4>(c, "sheet LT 32 M 16 (512 thr, 2/CU) 8 in 8 out");
     run_sheet<64, 16, 16, 8, 8, 4>(c, "sheet LT 64 M 16 (1024 thr, 1/CU) 8 in 8 out");
+    run_sheet<64, 16, 16, 8, 8, 4, 4, 0>(c, "sheet LT 64: 8 in, 4 read again, 8 out");
+    run_sheet<64, 16, 16, 8, 8, 4, 4, 1>(c, "sheet LT 64: 8 in + o+-1 rows, 4 again, 8 out");
     run_sheet<32, 16, 16, 8, 0, 4>(c, "sheet LT 32 M 16 loads only (8 in)");
     run_sheet<64, 16, 16, 8, 0, 4>(c, "sheet LT 64 M 16 loads only (8 in)");
     run_sheet<32, 16, 16, 1, 8, 4>(c, "sheet LT 32 M 16 stores (1 in 8 out)");
