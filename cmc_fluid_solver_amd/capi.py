@@ -52,6 +52,7 @@ SYMBOLS = {
     "fs3d_comm_abort": (_i, [_vp]),
     "fs3d_last_step_timing": (_i, [_vp, C.POINTER(C.c_float), C.POINTER(_i)]),
     "fs3d_enable_timing": (_i, [_vp, _i]),
+    "fs3d_profiler_events": (_i, [_vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(_i)]),
     "fs3d_profile_sweep": (_i, [_vp, _i, _d, _i, _i, _i, C.POINTER(C.c_ulonglong), _i, C.POINTER(_i)]),
     "fs3d_last_sweep_kernel": (_i, [_vp, _i, C.POINTER(_i), C.POINTER(_i)]),
     "fs3d_version": (C.c_char_p, []),
@@ -208,6 +209,12 @@ class Solver:
             out[nm] = KERNEL_NAMES.get(k.value, str(k.value)) + ("-segmented" if sg.value & 1 else "") + \
                 {0: "", 1: "+pipelined-ranks", 2: "+reduced-interface"}[(sg.value >> 1) & 3]
         return out
+
+    def profiler_events(self):
+        """{event name of the reference's Profiler: (total ms, count)} since enable_timing(True)"""
+        names, ms, n = (C.c_char_p * 9)(), (C.c_float * 9)(), (C.c_int * 9)()
+        self._chk(self.lib.fs3d_profiler_events(self.h, names, ms, n))
+        return {names[k].decode(): (ms[k], n[k]) for k in range(9)}
 
     def enable_timing(self, on=True):
         self._chk(self.lib.fs3d_enable_timing(self.h, int(on)))

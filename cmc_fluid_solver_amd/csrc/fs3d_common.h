@@ -111,8 +111,11 @@ struct fs3d_ctx {
     std::vector<hipEvent_t> ev;
     size_t ev_used = 0;
     std::vector<int> ev_class;
-    float t_ms[4] = {0, 0, 0, 0};
-    int t_n[4] = {0, 0, 0, 0};
+    // device time per event of the reference's Profiler vocabulary (AdiSolver3D.cpp:297-367, 555-680): 0 SolveSegments_Z, 1 _Y, 2 _X,
+    // 3 CopyLayer, 4 MergeLayer, 5 EvalDivError, 6 UpdateBoundaries, 7 syncHalos
+    float t_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int t_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double t_create_segments_ms = 0;       // host time of fs3d_upload_nodes (CreateSegments + Init_GPU)
     unsigned long long *stamps = nullptr;   // device buffer for fs3d_profile_sweep
     int stamps_cap = 0;
     // comm

@@ -2,6 +2,7 @@
 // context, geometry tables, auxiliary kernels and the time-step orchestration.
 // The line-sweep kernels live in kernels_line.hip / kernels_pipe.hip.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -303,14 +304,30 @@ extern "C" fs3d_status fs3d_enable_timing(fs3d_ctx *c, int on)
 {
     if (!c) return FS3D_ERR_INVALID;
     c->timing = on != 0;
-    for (int k = 0; k < 4; k++) { c->t_ms[k] = 0; c->t_n[k] = 0; }
+    for (int k = 0; k < 8; k++) { c->t_ms[k] = 0; c->t_n[k] = 0; }
     return FS3D_OK;
 }
 
 extern "C" fs3d_status fs3d_last_step_timing(fs3d_ctx *c, float ms[4], int n[4])
 {
     if (!c) return FS3D_ERR_INVALID;
-    for (int k = 0; k < 4; k++) { if (ms) ms[k] = c->t_ms[k]; if (n) n[k] = c->t_n[k]; }
+    for (int k = 0; k < 3; k++) { if (ms) ms[k] = c->t_ms[k]; if (n) n[k] = c->t_n[k]; }
+    float rest = 0; int nrest = 0;
+    for (int k = 3; k < 8; k++) { rest += c->t_ms[k]; nrest += c->t_n[k]; }
+    if (ms) ms[3] = rest;
+    if (n) n[3] = nrest;
+    return FS3D_OK;
+}
+
+static const char *const k_event_names[FS3D_N_EVENTS] = {"SolveSegments_Z", "SolveSegments_Y", "SolveSegments_X", "CopyLayer", "MergeLayer",
+                                                         "EvalDivError", "UpdateBoundaries", "syncHalos", "CreateSegments"};
+extern "C" fs3d_status fs3d_profiler_events(fs3d_ctx *c, const char *names[FS3D_N_EVENTS], float ms[FS3D_N_EVENTS], int n[FS3D_N_EVENTS])
+{
+    if (!c) return FS3D_ERR_INVALID;
+    for (int k = 0; k < 8; k++) { if (names) names[k] = k_event_names[k]; if (ms) ms[k] = c->t_ms[k]; if (n) n[k] = c->t_n[k]; }
+    if (names) names[8] = k_event_names[8];
+    if (ms) ms[8] = (float)c->t_create_segments_ms;
+    if (n) n[8] = c->have_nodes ? 1 : 0;
     return FS3D_OK;
 }
 
@@ -447,9 +464,12 @@ extern "C" fs3d_status fs3d_upload_nodes(fs3d_ctx *c, const uint8_t *type, const
 {
     if (!c) return FS3D_ERR_INVALID;
     if (!type || !bc_vel || !bc_temp || !vx || !vy || !vz || !T) return fail(c, FS3D_ERR_INVALID, "fs3d_upload_nodes: NULL array");
-    if (c->prec == FS3D_F32)
-        return upload_nodes_impl<float>(c, type, bc_vel, bc_temp, (const float *)vx, (const float *)vy, (const float *)vz, (const float *)T, n_seg_out);
-    return upload_nodes_impl<double>(c, type, bc_vel, bc_temp, (const double *)vx, (const double *)vy, (const double *)vz, (const double *)T, n_seg_out);
+    const auto t0 = std::chrono::steady_clock::now();
+    const fs3d_status st = c->prec == FS3D_F32
+        ? upload_nodes_impl<float>(c, type, bc_vel, bc_temp, (const float *)vx, (const float *)vy, (const float *)vz, (const float *)T, n_seg_out)
+        : upload_nodes_impl<double>(c, type, bc_vel, bc_temp, (const double *)vx, (const double *)vy, (const double *)vz, (const double *)T, n_seg_out);
+    c->t_create_segments_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return st;
 }
 
 // ---------------------------------------------------------------------------------
@@ -700,17 +720,23 @@ static fs3d_status sweep_buffers(fs3d_ctx *c, int dir, double dt, int b_cur, int
 {
     SweepParams<R> p;
     fill_params<R>(c, p, dir, dt, b_cur, b_temp, b_next, b_tout, merge);
-    rec_begin(c, dir == 2 ? 0 : (dir == 1 ? 1 : 2));
-    if (halo) {
+    const int cls = dir == 2 ? 0 : (dir == 1 ? 1 : 2);
+    if (halo && c->nranks > 1) {
         fs3d_status so;
-        if (sweep_overlapped<R>(c, dir, p, b_temp, so)) {
+        rec_begin(c, cls);
+        if (sweep_overlapped<R>(c, dir, p, b_temp, so)) {      // the exchange runs beside the interior planes: inside the sweep's time
             rec_end(c);
             if (so) return so;
             HIPCHK(c, hipGetLastError());
             return FS3D_OK;
         }
-        if ((so = fs3d_comm_halo_exchange(c, b_temp, 4))) { rec_end(c); return so; }
+        if (c->timing) { c->ev_used -= 2; c->ev_class.pop_back(); }      // nothing was launched: drop the event pair
+        rec_begin(c, 7);                                       // syncHalos_{X,Y,Z} (AdiSolver3D.cpp:608)
+        so = fs3d_comm_halo_exchange(c, b_temp, 4);
+        rec_end(c);
+        if (so) return so;
     }
+    rec_begin(c, cls);
     if (dir == 0 && c->nranks > 1) {
         // reduced-interface form (all ranks at once) unless bit-equality with the sequential recurrence was asked for
         const bool reduced = c->opt_xsolve == 2 || (c->opt_xsolve == 0 && (c->opt_kernel == FS3D_SWEEP_AUTO || c->opt_kernel == FS3D_SWEEP_PART));
@@ -790,7 +816,7 @@ extern "C" fs3d_status fs3d_profile_sweep(fs3d_ctx *c, int dir, double dt, int l
 template <typename R>
 static fs3d_status merge_buffers(fs3d_ctx *c, int b_src, int b_dest)
 {
-    rec_begin(c, 3);
+    rec_begin(c, 4);
     hipLaunchKernelGGL((k_merge<R>), dim3(grid_for(c->ncell, 256)), dim3(256), 0, c->stream, c->code, c->ncell,
                        fld<R>(c, b_src, 0), fld<R>(c, b_src, 1), fld<R>(c, b_src, 2), fld<R>(c, b_src, 3),
                        fld<R>(c, b_dest, 0), fld<R>(c, b_dest, 1), fld<R>(c, b_dest, 2), fld<R>(c, b_dest, 3));
@@ -804,7 +830,7 @@ static fs3d_status update_boundaries_impl(fs3d_ctx *c)
 {
     if (!c->n_bnd) return FS3D_OK;
     const int b = c->slot[FS3D_LAYER_CUR];
-    rec_begin(c, 3);
+    rec_begin(c, 6);
     hipLaunchKernelGGL((k_impose_list<R>), dim3((c->n_bnd + 255) / 256), dim3(256), 0, c->stream, c->bnd_idx, c->n_bnd,
                        (const R *)c->bnd_val[0], (const R *)c->bnd_val[1], (const R *)c->bnd_val[2], (const R *)c->bnd_val[3],
                        fld<R>(c, b, 0), fld<R>(c, b, 1), fld<R>(c, b, 2), fld<R>(c, b, 3));
@@ -830,7 +856,7 @@ static fs3d_status div_error_enqueue(fs3d_ctx *c, int layer)
     const int b = c->slot[layer];
     // the last slab skips its final plane (TimeLayer3D.h:606); inner slabs need the i-1 ghost (halo exchanged by caller)
     const int i_end = (c->x_offset + c->dimx == c->dimx_global) ? c->dimx - 1 : c->dimx;
-    rec_begin(c, 3);
+    rec_begin(c, 5);
     hipLaunchKernelGGL((k_div_error<R>), dim3(c->red_blocks), dim3(256), 0, c->stream, c->code,
                        (const R *)fld<R>(c, b, 0), (const R *)fld<R>(c, b, 1), (const R *)fld<R>(c, b, 2),
                        c->dimx, c->dimy, c->dimz, i_end, c->x_offset == 0 ? 1 : 0, (R)c->gdx, (R)c->gdy, (R)c->gdz, c->red_buf + 2);

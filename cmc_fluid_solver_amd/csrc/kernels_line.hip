@@ -212,25 +212,41 @@ __global__ void __launch_bounds__(256) k_xiface(SweepParams<R> p, R *out)
     if (tid >= nl) return;
     const int n = p.dimx;
     RowUVWT<R> r;
+    // Rows are built four at a time: their loads do not depend on the recurrence, so four cells' worth are in flight
+    // together (a thin slab gives every thread a short, latency-bound walk: 31 cells of a 32-plane slab).
+    constexpr int B = 4;
+    RowUVWT<R> rb[B];
     // down: x[n-2] = dp - lp X_{r-1} - cp X_r
     R cpv = R(0), lpv = R(-1), cpt = R(0), lpt = R(-1), dp[4] = {R(0), R(0), R(0), R(0)};
-    for (int s = 0; s < n - 1; s++) {
-        xrow<R>(p, tid + s * p.plane, r);
-        const R dv = r.b_v - r.a_v * cpv, dt = r.b_t - r.a_t * cpt;
-        dp[0] = (r.d[0] - r.a_v * dp[0]) / dv; dp[1] = (r.d[1] - r.a_v * dp[1]) / dv; dp[2] = (r.d[2] - r.a_v * dp[2]) / dv;
-        dp[3] = (r.d[3] - r.a_t * dp[3]) / dt;
-        lpv = -r.a_v * lpv / dv; lpt = -r.a_t * lpt / dt;
-        cpv = r.c_v / dv; cpt = r.c_t / dt;
+    for (int s0 = 0; s0 < n - 1; s0 += B) {
+#pragma unroll
+        for (int b = 0; b < B; b++) xrow<R>(p, tid + (long long)(s0 + b < n - 1 ? s0 + b : n - 2) * p.plane, rb[b]);
+#pragma unroll
+        for (int b = 0; b < B; b++) {
+            if (s0 + b >= n - 1) break;
+            const RowUVWT<R> &r = rb[b];
+            const R dv = r.b_v - r.a_v * cpv, dt = r.b_t - r.a_t * cpt;
+            dp[0] = (r.d[0] - r.a_v * dp[0]) / dv; dp[1] = (r.d[1] - r.a_v * dp[1]) / dv; dp[2] = (r.d[2] - r.a_v * dp[2]) / dv;
+            dp[3] = (r.d[3] - r.a_t * dp[3]) / dt;
+            lpv = -r.a_v * lpv / dv; lpt = -r.a_t * lpt / dt;
+            cpv = r.c_v / dv; cpt = r.c_t / dt;
+        }
     }
     // up: x[0] = ep - ap X_{r-1} - up X_r
     R apv = R(0), upv = R(-1), apt = R(0), upt = R(-1), ep[4] = {R(0), R(0), R(0), R(0)};
-    for (int s = n - 2; s >= 0; s--) {
-        xrow<R>(p, tid + s * p.plane, r);
-        const R dv = r.b_v - r.c_v * apv, dt = r.b_t - r.c_t * apt;
-        ep[0] = (r.d[0] - r.c_v * ep[0]) / dv; ep[1] = (r.d[1] - r.c_v * ep[1]) / dv; ep[2] = (r.d[2] - r.c_v * ep[2]) / dv;
-        ep[3] = (r.d[3] - r.c_t * ep[3]) / dt;
-        upv = -r.c_v * upv / dv; upt = -r.c_t * upt / dt;
-        apv = r.a_v / dv; apt = r.a_t / dt;
+    for (int s0 = n - 2; s0 >= 0; s0 -= B) {
+#pragma unroll
+        for (int b = 0; b < B; b++) xrow<R>(p, tid + (long long)(s0 - b >= 0 ? s0 - b : 0) * p.plane, rb[b]);
+#pragma unroll
+        for (int b = 0; b < B; b++) {
+            if (s0 - b < 0) break;
+            const RowUVWT<R> &r = rb[b];
+            const R dv = r.b_v - r.c_v * apv, dt = r.b_t - r.c_t * apt;
+            ep[0] = (r.d[0] - r.c_v * ep[0]) / dv; ep[1] = (r.d[1] - r.c_v * ep[1]) / dv; ep[2] = (r.d[2] - r.c_v * ep[2]) / dv;
+            ep[3] = (r.d[3] - r.c_t * ep[3]) / dt;
+            upv = -r.c_v * upv / dv; upt = -r.c_t * upt / dt;
+            apv = r.a_v / dv; apt = r.a_t / dt;
+        }
     }
     xrow<R>(p, tid + (long long)(n - 1) * p.plane, r);
     R *o = out + tid;

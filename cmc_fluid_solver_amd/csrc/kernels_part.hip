@@ -331,7 +331,7 @@ __global__ void __launch_bounds__(LT * NCH, WPS) k_sweep_part(SweepParams<R> p, 
                 }
             }
             q[i] = qq; dU[i] = dd[0]; dV[i] = dd[1]; dW[i] = dd[2];
-            if (KT) {
+            if constexpr (KT) {
 #pragma unroll
                 for (int f = 0; f < 4; f++) tkeep[f][i] = Tc[f];
             }
@@ -908,8 +908,12 @@ static bool part_launch_z(fs3d_ctx *c, const SweepParams<float> &p)
 {
     constexpr int LI = 64 / LPL;
     static const int lg_env = getenv("FS3D_PART_ZLG") ? atoi(getenv("FS3D_PART_ZLG")) : 0;     // kernel experiments
-    int LG = lg_env > 0 ? lg_env : 8;
     const int rows = (p.dimy + LI - 1) / LI;              // rows of LI lines per plane
+    const int npl = p.o_count ? p.o_count : p.dimx;
+    // 8 rows per wave where the grid is large enough to give every CU several workgroups that way; fewer on small grids /
+    // thin slabs (a 64^3 grid would otherwise launch 32 workgroups for 256 CUs)
+    int LG = lg_env > 0 ? lg_env : 8;
+    while (LG > 1 && (long long)((rows + LG - 1) / LG) * npl < 4096) LG >>= 1;
     if (LG > rows) LG = rows;
     const int n_grp = (rows + LG - 1) / LG;
     const long long tasks = (long long)n_grp * (p.o_count ? p.o_count : p.dimx);

@@ -103,7 +103,11 @@ public:
     // device time per event class since EnableTiming(true): 0 sweeps Z, 1 sweeps Y, 2 sweeps X, 3 everything else
     void EnableTiming(bool on) { chk(fs3d_enable_timing(ctx_, on ? 1 : 0)); }
     void Timings(float ms[4], int count[4]) { chk(fs3d_last_step_timing(ctx_, ms, count)); }
+    // the same under the reference Profiler's event names (Common/Profiler.h; AdiSolver3D.cpp:297-367, 555-680)
+    void ProfilerEvents(const char *names[FS3D_N_EVENTS], float ms[FS3D_N_EVENTS], int count[FS3D_N_EVENTS]) { chk(fs3d_profiler_events(ctx_, names, ms, count)); }
     double EvalDivError() { double e = 0; chk(fs3d_eval_div_error(ctx_, FS3D_LAYER_NEXT, &e, nullptr)); return e; }
+
+    fs3d_ctx *ctx() const { return ctx_; }              // for C-ABI calls the class does not wrap
 
     double diffError = 0.0;
     int numSegs[3] = {0, 0, 0};

@@ -10,6 +10,7 @@
 // There is no CPU backend here: without a GPU the run stops with the library's error.
 // --grid-only FILE: build the grid, dump it (dims, type, bc_vel, bc_temp, vx, vy, vz, T as raw arrays) and exit
 //   without touching the GPU -- used by the CPU tests to compare the C++ loader with its Python twin.
+#include <algorithm>
 #include <chrono>
 #include <condition_variable>
 #include <exception>
@@ -94,22 +95,30 @@ static int run(const std::string &data, const std::string &prefix, const fs3d::C
         }
     }
     const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    // the reference's Profiler table (Common/Profiler.h:90-131; events of AdiSolver3D.cpp:297-652).  The merges are part
-    // of the sweep kernels here; boundary lists, the cur->next copy and EvalDivError are the last row.
-    float ms[4]; int cnt[4];
-    solver.Timings(ms, cnt);
-    const char *ev[4] = {"SolveSegments_Z", "SolveSegments_Y", "SolveSegments_X", "Bounds+DivError"};
+    // the reference's Profiler table (Common/Profiler.h:90-131: sorted by total time, events that never ran are absent; event
+    // names of AdiSolver3D.cpp:297-367, 555-680).  Device times from HIP events; MergeLayer has no launches of its own while
+    // the merge is fused into the sweep kernels; CreateSegments is the host time of the geometry upload.
+    const char *names[FS3D_N_EVENTS]; float ms[FS3D_N_EVENTS]; int cnt[FS3D_N_EVENTS];
+    solver.ProfilerEvents(names, ms, cnt);
+    std::vector<int> order;
+    for (int e = 0; e < FS3D_N_EVENTS; e++) if (cnt[e]) order.push_back(e);
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return ms[a] > ms[b]; });
     double total = 0;
     if (csv) std::printf("\n%s,%s,%s,%s,\n", "Event Name", "Total (ms)", "Avg (ms)", "Count");
     else std::printf("\nProfiling data node(0):\n%16s%16s%16s%16s\n", "Event Name", "Total (ms)", "Avg (ms)", "Count");
-    for (int e = 0; e < 4; e++) {
-        if (!cnt[e]) continue;
-        if (csv) std::printf("%s,%.2f,%.2f,%i,\n", ev[e], ms[e], ms[e] / cnt[e], cnt[e]);
-        else std::printf("%16s%16.2f%16.2f%16i\n", ev[e], ms[e], ms[e] / cnt[e], cnt[e]);
+    for (int e : order) {
+        if (csv) std::printf("%s,%.2f,%.2f,%i,\n", names[e], ms[e], ms[e] / cnt[e], cnt[e]);
+        else std::printf("%16s%16.2f%16.2f%16i\n", names[e], ms[e], ms[e] / cnt[e], cnt[e]);
         total += ms[e];
     }
     if (csv) std::printf("%s,%.2f,sec\n", "Overall", total / 1000);
     else std::printf("%16s%16.2f sec\n", "Overall", total / 1000);
+    {
+        int kx, ky, kz, sg;
+        const char *kn[] = {"none", "line", "pipe", "part"};
+        fs3d_last_sweep_kernel(solver.ctx(), 0, &kx, &sg); fs3d_last_sweep_kernel(solver.ctx(), 1, &ky, &sg); fs3d_last_sweep_kernel(solver.ctx(), 2, &kz, &sg);
+        std::printf("Sweep kernels: X %s, Y %s, Z %s\n", kn[kx & 3], kn[ky & 3], kn[kz & 3]);
+    }
     std::printf("%ld steps in %.3f s: %.1f Mcells/s; %u layers in %s\n", steps, sec,
                 (double)grid.dimx * grid.dimy * grid.dimz * steps / sec / 1e6, nc.NumRecords(), out.c_str());
     return 0;

@@ -192,6 +192,12 @@ fs3d_status fs3d_comm_abort(fs3d_ctx *ctx);
  * on the context's stream: ms[0]=Z sweeps, [1]=Y sweeps, [2]=X sweeps, [3]=everything
  * else; n[] = number of launches in each class.  Profiler.h event names map onto these. */
 fs3d_status fs3d_last_step_timing(fs3d_ctx *ctx, float ms[4], int n[4]);
+/* The same device times under the event names of the reference's Profiler (Common/Profiler.h:44-134; StartEvent/StopEvent
+ * sites AdiSolver3D.cpp:297-367, 555-680): SolveSegments_Z/_Y/_X, CopyLayer, MergeLayer (zero launches while the merge is fused
+ * into the sweeps), EvalDivError, UpdateBoundaries, syncHalos, CreateSegments (host time of fs3d_upload_nodes).  names[] receives
+ * static strings.  The driver prints them as the reference's PrintTimings table. */
+#define FS3D_N_EVENTS 9
+fs3d_status fs3d_profiler_events(fs3d_ctx *ctx, const char *names[FS3D_N_EVENTS], float ms[FS3D_N_EVENTS], int n[FS3D_N_EVENTS]);
 /* enable/disable per-class event timing (adds 2 events per launch; default off) */
 fs3d_status fs3d_enable_timing(fs3d_ctx *ctx, int on);
 

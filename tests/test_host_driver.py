@@ -154,3 +154,19 @@ def test_driver_gpu_n_mode_equals_single_gpu(driver, nslabs, tmp_path):
     for v in ("u", "v", "w", "T", "time"):
         assert outs["one"][1][v].shape[0] == 3
         np.testing.assert_array_equal(outs["one"][1][v], outs["slabs"][1][v])
+
+
+@pytest.mark.gpu
+def test_driver_prints_the_reference_profiler_vocabulary(driver, tmp_path):
+    """The closing table of fs3d_run carries the reference Profiler's event names (Common/Profiler.h:90-133; StartEvent/StopEvent
+    sites AdiSolver3D.cpp:297-367, 555-680), sorted by total time, and names the sweep kernels that ran."""
+    data, conf = [os.path.join(INPUTS, f) for f in CASES["box_pipe"]]
+    out = subprocess.run([driver, data, str(tmp_path / "pp"), conf, "align", "GPU", "--steps", "12"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    tab = out.stdout[out.stdout.index("Profiling data node(0):"):]
+    for name in ("SolveSegments_X", "SolveSegments_Y", "SolveSegments_Z", "CopyLayer", "EvalDivError", "UpdateBoundaries", "CreateSegments", "Overall"):
+        assert name in tab, tab
+    rows = [l.split() for l in tab.splitlines()[2:] if l.strip() and not l.strip().startswith(("Overall", "Sweep", "12 steps"))]
+    totals = [float(r[1]) for r in rows if len(r) == 4]
+    assert totals == sorted(totals, reverse=True)
+    assert "Sweep kernels:" in out.stdout
