@@ -4,7 +4,9 @@
 //                                       (FluidSolver2D/Grid2D.cpp:109-372, 376-396)
 //   BBox2D::Build                       (Common/Geometry.h:455-486)
 //   Grid3D::LoadFromFile / Prepare2D    (FluidSolver3D/Grid3D.cpp:488-513, 608-668)
-// Single-frame inputs (all shipped 3D examples); multi-frame interpolation is not implemented (throws).
+// Multi-frame inputs (moving walls, data/3D/large_tests/heart_us): all frames are read, border velocities come from the move
+// between consecutive frames, the bounding box covers all frames, Prepare(time) interpolates a sub-frame.  The reference's 3D
+// time loop prepares the grid once, at time 0 (`grid->Prepare(t)` is commented out, FluidSolver3D.cpp:237).
 // Python twin with the same pins (grid dims, NODE_IN counts of SURVEY.md): cmc_fluid_solver_amd/shape2d.py.
 #pragma once
 #include <algorithm>
@@ -27,7 +29,7 @@ struct Shape2DFrame {
     std::vector<Shape> shapes;
 };
 
-// FluidSolver2D::Grid2D for one frame (Grid2D.h:42-104)
+// FluidSolver2D::Grid2D (Grid2D.h:42-104)
 struct Grid2D {
     static constexpr float GRID_SCALE_FACTOR = 0.001f, BBOX_PADDING = 0.02f, INF = 1e10f;   // Grid2D.h:31, Geometry.h:22-24
     int dimx = 0, dimy = 0;
@@ -43,7 +45,10 @@ struct Grid2D {
         return (float)std::atof(tok.c_str());
     }
 
-    void Load(const std::string &path, double dx_, double dy_, double startT, bool align)
+    std::vector<Shape2DFrame> frames;    // every frame of the file; gx/gy = grid coordinates (Init)
+    float startT = 0;
+
+    void Load(const std::string &path, double dx_, double dy_, double startT_, bool align, double time = 0.0)
     {
         std::ifstream in(path.c_str());
         if (!in) throw std::runtime_error("cannot open Shape2D file " + path);
@@ -52,33 +57,53 @@ struct Grid2D {
         size_t i = 0;
         auto next = [&]() -> const std::string & { if (i >= t.size()) throw std::runtime_error("Shape2D file ends early"); return t[i++]; };
         const int num_frames = std::atoi(next().c_str());
-        if (num_frames != 1) throw std::runtime_error("multi-frame Shape2D inputs (frame interpolation) are not supported");
-        Shape2DFrame fr;
-        fr.duration = num(next());
-        const int nshapes = std::atoi(next().c_str());
-        for (int s = 0; s < nshapes; s++) {
-            Shape2DFrame::Shape sh;
-            const int npts = std::atoi(next().c_str());
-            for (int p = 0; p < npts; p++) {
-                const float x = num(next()), y = num(next());
-                sh.px.push_back(x * GRID_SCALE_FACTOR); sh.py.push_back(y * GRID_SCALE_FACTOR);
+        if (num_frames < 1) throw std::runtime_error("Shape2D file holds no frames");
+        frames.assign(num_frames, Shape2DFrame());
+        for (auto &fr : frames) {                                    // Grid2D.cpp:282-318
+            fr.duration = num(next());
+            const int nshapes = std::atoi(next().c_str());
+            for (int s = 0; s < nshapes; s++) {
+                Shape2DFrame::Shape sh;
+                const int npts = std::atoi(next().c_str());
+                for (int p = 0; p < npts; p++) {
+                    const float x = num(next()), y = num(next());
+                    sh.px.push_back(x * GRID_SCALE_FACTOR); sh.py.push_back(y * GRID_SCALE_FACTOR);
+                }
+                sh.active = next()[0] == 'M';                        // "Motion vx vy" | "Passive"
+                float vx = 0, vy = 0;
+                if (sh.active) { vx = num(next()); vy = num(next()); }
+                sh.vx.assign(npts, vx * GRID_SCALE_FACTOR);
+                sh.vy.assign(npts, vy * GRID_SCALE_FACTOR);
+                fr.shapes.push_back(sh);
             }
-            sh.active = next()[0] == 'M';                        // "Motion vx vy" | "Passive"
-            float vx = 0, vy = 0;
-            if (sh.active) { vx = num(next()); vy = num(next()); }
-            // one frame: ComputeBorderVelocities (Grid2D.cpp:376-396) leaves passive shapes at rest
-            sh.vx.assign(npts, sh.active ? vx * GRID_SCALE_FACTOR : 0.0f);
-            sh.vy.assign(npts, sh.active ? vy * GRID_SCALE_FACTOR : 0.0f);
-            fr.shapes.push_back(sh);
         }
-        dx = dx_; dy = dy_; duration = fr.duration;
-        // BBox2D::Build (Geometry.h:455-486)
-        float pminx = INF, pminy = INF, pmaxx = -INF, pmaxy = -INF;
-        for (auto &sh : fr.shapes)
-            for (size_t p = 0; p < sh.px.size(); p++) {
-                pminx = std::min(pminx, sh.px[p]); pminy = std::min(pminy, sh.py[p]);
-                pmaxx = std::max(pmaxx, sh.px[p]); pmaxy = std::max(pmaxy, sh.py[p]);
+        for (size_t f = 1; f < frames.size(); f++) {
+            if (frames[f].shapes.size() != frames[0].shapes.size()) throw std::runtime_error("Shape2D: frames differ in their number of shapes");
+            for (size_t s = 0; s < frames[f].shapes.size(); s++)
+                if (frames[f].shapes[s].px.size() != frames[0].shapes[s].px.size()) throw std::runtime_error("Shape2D: a shape changes its number of points between frames");
+        }
+        // ComputeBorderVelocities(j) for every frame, in order (Grid2D.cpp:365-366, 375-396): the velocities of frame j+1 from the
+        // move j -> j+1.  One frame: next == frame, every difference is 0: passive shapes at rest, active ones keep theirs.
+        for (size_t j = 0; j < frames.size(); j++) {
+            Shape2DFrame &a = frames[j], &b = frames[(j + 1) % frames.size()];
+            const float m = (float)(1 / (double)a.duration);
+            for (size_t s = 0; s < a.shapes.size(); s++) {
+                const auto &sa = a.shapes[s];
+                auto &sb = b.shapes[s];
+                for (size_t p = 0; p < sa.px.size(); p++)
+                    if (!sa.active) { sb.vx[p] = (float)(sb.px[p] - sa.px[p]) * m; sb.vy[p] = (float)(sb.py[p] - sa.py[p]) * m; }
+                    else { sb.vx[p] = mix(sb.vx[p], 1.0f, sa.px[p] - sb.px[p], m); sb.vy[p] = mix(sb.vy[p], 1.0f, sa.py[p] - sb.py[p], m); }
             }
+        }
+        dx = dx_; dy = dy_; duration = frames[0].duration; startT = (float)startT_;
+        // BBox2D::Build over the points of all frames (Geometry.h:455-486)
+        float pminx = INF, pminy = INF, pmaxx = -INF, pmaxy = -INF;
+        for (auto &fr : frames)
+            for (auto &sh : fr.shapes)
+                for (size_t p = 0; p < sh.px.size(); p++) {
+                    pminx = std::min(pminx, sh.px[p]); pminy = std::min(pminy, sh.py[p]);
+                    pmaxx = std::max(pmaxx, sh.px[p]); pmaxy = std::max(pmaxy, sh.py[p]);
+                }
         const float wx = pmaxx - pminx, wy = pmaxy - pminy;
         pminx = pminx - wx * BBOX_PADDING; pminy = pminy - wy * BBOX_PADDING;
         pmaxx = pmaxx + wx * BBOX_PADDING; pmaxy = pmaxy + wy * BBOX_PADDING;
@@ -88,14 +113,57 @@ struct Grid2D {
         dimy = (int)std::ceil((double)(float)(pmaxy - pminy) / dy) + 1;
         if (align) { dimx = AlignBy32(dimx); dimy = AlignBy32(dimy); }
         const float fdx = (float)dx, fdy = (float)dy;
-        for (auto &sh : fr.shapes) {
-            sh.gx.resize(sh.px.size()); sh.gy.resize(sh.px.size());
-            for (size_t p = 0; p < sh.px.size(); p++) { sh.gx[p] = (float)(sh.px[p] - pminx) / fdx; sh.gy[p] = (float)(sh.py[p] - pminy) / fdy; }
+        for (auto &fr : frames)
+            for (auto &sh : fr.shapes) {
+                sh.gx.resize(sh.px.size()); sh.gy.resize(sh.px.size());
+                for (size_t p = 0; p < sh.px.size(); p++) { sh.gx[p] = (float)(sh.px[p] - pminx) / fdx; sh.gy[p] = (float)(sh.py[p] - pminy) / fdy; }
+            }
+        Prepare(time);
+    }
+
+    // ---- frames in time (Grid2D.cpp:447-519)
+    int GetFramesNum() const { return (int)frames.size(); }
+    double GetCycleLenght() const { double r = 0; for (auto &fr : frames) r += fr.duration; return r; }
+    int GetFrame(double time) const { double r, a0, a1; return Locate(time, r, a0, a1); }
+    float GetLayerTime(double time) const { double r, a0, a1; Locate(time, r, a0, a1); return (float)(a1 - r); }
+
+    // Grid2D::Prepare(time) -> ComputeSubframe(frame, substep) -> Build (Grid2D.cpp:398-461)
+    void Prepare(double time)
+    {
+        double r, a0, a1;
+        const int frame = Locate(time, r, a0, a1);
+        const double substep = (r - a0) / (a1 - a0), isubstep = 1 - substep;
+        const Shape2DFrame &f0 = frames[frame], &f1 = frames[(frame + 1) % frames.size()];
+        const float s = (float)substep, is = (float)isubstep;
+        Shape2DFrame sub;
+        for (size_t q = 0; q < f0.shapes.size(); q++) {
+            const auto &sa = f0.shapes[q], &sb = f1.shapes[q];
+            Shape2DFrame::Shape sh;
+            sh.active = sa.active;
+            const size_t n = sa.px.size();
+            sh.gx.resize(n); sh.gy.resize(n); sh.vx.resize(n); sh.vy.resize(n);
+            for (size_t p = 0; p < n; p++) {
+                sh.gx[p] = mix(sa.gx[p], is, sb.gx[p], s); sh.gy[p] = mix(sa.gy[p], is, sb.gy[p], s);
+                sh.vx[p] = mix(sa.vx[p], is, sb.vx[p], s); sh.vy[p] = mix(sa.vy[p], is, sb.vy[p], s);
+            }
+            sub.shapes.push_back(sh);
         }
-        Build(fr, (float)startT);
+        Build(sub, startT);
     }
 
 private:
+    // a*wa + b*wb with each product and the sum rounded to float (no contraction into an fma)
+    static float mix(float a, float wa, float b, float wb) { volatile float x = a * wa, y = b * wb; return x + y; }
+    int Locate(double time, double &r, double &a0, double &a1) const
+    {
+        std::vector<double> a(frames.size() + 1, 0.0);
+        for (size_t i = 1; i <= frames.size(); i++) a[i] = a[i - 1] + frames[i - 1].duration;
+        r = std::fmod(time, a[frames.size()]);
+        int frame = 0;
+        for (size_t i = 1; i < frames.size(); i++) if (a[i] < r) frame = (int)i;
+        a0 = a[frame]; a1 = a[frame + 1];
+        return frame;
+    }
     size_t id(int x, int y) const { return (size_t)x * dimy + y; }
     // Grid2D::RasterLine (Grid2D.cpp:117-153), bc_noslip == true (Grid3D.cpp:28)
     void RasterLine(float p1x, float p1y, float p2x, float p2y, float v1x, float v1y, float v2x, float v2y, uint8_t color, float startT)

@@ -62,8 +62,8 @@ static int run(const std::string &data, const std::string &prefix, const fs3d::C
     solver.Init(device, grid, params);
     std::printf("Segments: %i %i %i (x, y, z)\n", solver.numSegs[0], solver.numSegs[1], solver.numSegs[2]);
 
-    const int frames = 1;                                              // single-frame Shape2D inputs
-    const double length = g2.duration;
+    const int frames = g2.GetFramesNum();                              // FluidSolver3D.cpp:194-195
+    const double length = g2.GetCycleLenght();
     const double dt = length / (frames * cfg.time_steps);              // :196
     const double finaltime = length * cfg.cycles;
     const std::string out = prefix + "_res.nc";
@@ -77,16 +77,21 @@ static int run(const std::string &data, const std::string &prefix, const fs3d::C
     const auto t0 = std::chrono::steady_clock::now();
     double t = dt;
     long steps = 0;
+    int lastframe = -1;
+    // the geometry is frame 0's for the whole run: the reference prepares the grid once, before the loop (grid->Prepare(0), :226;
+    // the per-step grid->Prepare(t) is commented out, :237) -- the frame only restarts the substep counter
     for (int i = 0; t < finaltime && (max_steps < 0 || steps < max_steps); t += dt, i++, steps++) {
+        const int currentframe = g2.GetFrame(t);                                                         // :229-236
+        if (currentframe != lastframe) { lastframe = currentframe; i = 0; }
         solver.UpdateBoundaries();                                                                       // :244
         solver.TimeStep((FTYPE)dt, cfg.num_global, cfg.num_local, (i % 10 == 0) || (t + dt >= finaltime)); // :245
         std::printf("\rerr = %.8f,", solver.diffError);                                                  // AdiSolver3D.cpp:376
         const float elapsed = std::chrono::duration<float>(std::chrono::steady_clock::now() - t0).count();
         const float perres = (float)t * 100 / (float)finaltime;                                          // PrintTimeStepInfo, IO.h:455-478
-        if (perres < 2) std::printf(" frame %i\tsubstep %i\t%i%%\t(----- left)", 0, i, (int)perres);
+        if (perres < 2) std::printf(" frame %i\tsubstep %i\t%i%%\t(----- left)", currentframe, i, (int)perres);
         else {
             const float left = elapsed * (100 - perres) / perres;
-            std::printf(" frame %i\tsubstep %i\t%i%%\t(%i h %i m %i s left)", 0, i, (int)perres, ((int)left) / 3600, (((int)left) / 60) % 60, ((int)left) % 60);
+            std::printf(" frame %i\tsubstep %i\t%i%%\t(%i h %i m %i s left)", currentframe, i, (int)perres, ((int)left) / 3600, (((int)left) / 60) % 60, ((int)left) % 60);
         }
         std::fflush(stdout);
         if ((i % cfg.out_time_steps) == 0) {                                                             // :254-264
@@ -149,7 +154,7 @@ static int run_slabs(const fs3d::Grid3D<FTYPE> &grid, const fs3d::Grid2D &g2, co
     using namespace fs3d;
     FluidParams<FTYPE> params = cfg.useNormalizedParams ? FluidParams<FTYPE>(cfg.Re, cfg.Pr, cfg.lambda)
                                                         : FluidParams<FTYPE>(cfg.viscosity, cfg.density, cfg.R_specific, cfg.k, cfg.cv);
-    const double length = g2.duration, dt = length / (1 * cfg.time_steps), finaltime = length * cfg.cycles;
+    const double length = g2.GetCycleLenght(), dt = length / (g2.GetFramesNum() * cfg.time_steps), finaltime = length * cfg.cycles;
     const std::string out = prefix + "_res.nc";
     NetCDF3Writer nc;
     const float bbox[6] = {g2.bbox[0], g2.bbox[1], 0.0f, g2.bbox[2], g2.bbox[3], (float)cfg.depth};
@@ -174,10 +179,13 @@ static int run_slabs(const fs3d::Grid3D<FTYPE> &grid, const fs3d::Grid2D &g2, co
                 if (r == 0) std::printf("Slabs: %d x-slabs of %d..%d planes\n", nslabs, q, q + (rem ? 1 : 0));
                 double t = dt;
                 long steps = 0;
+                int lastframe = -1;
                 for (int i = 0; t < finaltime && (max_steps < 0 || steps < max_steps); t += dt, i++, steps++) {
+                    const int currentframe = g2.GetFrame(t);
+                    if (currentframe != lastframe) { lastframe = currentframe; i = 0; }
                     solver.UpdateBoundaries();
                     solver.TimeStep((FTYPE)dt, cfg.num_global, cfg.num_local, (i % 10 == 0) || (t + dt >= finaltime));
-                    if (r == 0) { std::printf("\rerr = %.8f, frame %i\tsubstep %i\t%i%%", solver.diffError, 0, i, (int)((float)t * 100 / (float)finaltime)); std::fflush(stdout); }
+                    if (r == 0) { std::printf("\rerr = %.8f, frame %i\tsubstep %i\t%i%%", solver.diffError, currentframe, i, (int)((float)t * 100 / (float)finaltime)); std::fflush(stdout); }
                     if ((i % cfg.out_time_steps) == 0) {
                         // each slab's part of `next` at full resolution (NODE_OUT stamped 99999), then FilterToArrays on the
                         // assembled layer (TimeLayer3D.h:819-924: nearest-neighbour down-sample)

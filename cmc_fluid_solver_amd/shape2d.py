@@ -7,7 +7,10 @@ the Node array the solver consumes:
   RasterLine / FloodFill            (FluidSolver2D/Grid2D.cpp:109-372, 268-372, 376-480)
   BBox2D::Build                     (Common/Geometry.h:455-486)
   Grid3D::LoadFromFile / Prepare2D  (FluidSolver3D/Grid3D.cpp:488-513, 608-668)
-Single-frame inputs (all shipped 3D examples) are supported; multi-frame interpolation is not.
+Multi-frame inputs (moving walls, e.g. data/3D/large_tests/heart_us): all frames are read, the border velocities of every
+frame come from the frame before it (ComputeBorderVelocities), the bounding box covers all frames, and the grid is built from
+Prepare(time) = ComputeSubframe(frame, substep).  The reference's 3D time loop prepares the grid once, at time 0 (the
+per-step `grid->Prepare(t)` is commented out, FluidSolver3D.cpp:237): the geometry is frame 0 with frame 0's border velocities.
 Pins: tests/test_grid_loader.py checks grid dims and NODE_IN counts against the reference outputs
 recorded in SURVEY.md sections 8c/8d.
 """
@@ -62,34 +65,75 @@ def parse_shape2d(text):
 class Grid2D:
     """FluidSolver2D::Grid2D for one frame (Grid2D.h:42-104)."""
 
-    def __init__(self, frames, dx, dy, startT, align):
-        if len(frames) != 1:
-            raise NotImplementedError("multi-frame Shape2D inputs (frame interpolation) are not supported")
+    def __init__(self, frames, dx, dy, startT, align, time=0.0):
         self.dx, self.dy, self.startT = dx, dy, startT
-        fr = frames[0]
-        self.duration = fr["duration"]
-        # ComputeBorderVelocities (Grid2D.cpp:376-396) with one frame: next == frame, every point difference is 0,
-        # so passive shapes get velocity 0 and active ones keep theirs
-        for sh in fr["shapes"]:
-            if not sh["active"]:
-                sh["vel"] = [(F(0), F(0)) for _ in sh["points"]]
-        # BBox2D::Build (Geometry.h:455-486)
-        xs = [p[0] for sh in fr["shapes"] for p in sh["points"]]
-        ys = [p[1] for sh in fr["shapes"] for p in sh["points"]]
+        self.frames = frames
+        self.num_frames = nf = len(frames)
+        self.duration = frames[0]["duration"]
+        # ComputeBorderVelocities(j) for every frame j, in order (Grid2D.cpp:375-396, called at :365-366): the velocities of
+        # frame j+1 -- passive shapes: (P[j+1] - P[j]) / duration[j]; active ones add (P[j] - P[j+1]) / duration[j].
+        # One frame: next == frame, every difference is 0: passive shapes at rest, active ones keep theirs.
+        for j in range(nf):
+            nxt = frames[(j + 1) % nf]
+            m = 1.0 / frames[j]["duration"]
+            for sa, sb in zip(frames[j]["shapes"], nxt["shapes"]):
+                if not sa["active"]:
+                    sb["vel"] = [(F(F(pb[0] - pa[0]) * F(m)), F(F(pb[1] - pa[1]) * F(m))) for pa, pb in zip(sa["points"], sb["points"])]
+                else:
+                    sb["vel"] = [(F(v[0] + F(F(pa[0] - pb[0]) * F(m))), F(v[1] + F(F(pa[1] - pb[1]) * F(m))))
+                                 for v, pa, pb in zip(sb["vel"], sa["points"], sb["points"])]
+        # BBox2D::Build over all frames (Geometry.h:455-486)
+        xs = [p[0] for fr in frames for sh in fr["shapes"] for p in sh["points"]]
+        ys = [p[1] for fr in frames for sh in fr["shapes"] for p in sh["points"]]
         pminx, pminy, pmaxx, pmaxy = min(xs + [INF]), min(ys + [INF]), max(xs + [F(-INF)]), max(ys + [F(-INF)])
         wx, wy = F(pmaxx - pminx), F(pmaxy - pminy)
         pminx, pminy = F(pminx - F(wx * BBOX_PADDING)), F(pminy - F(wy * BBOX_PADDING))
         pmaxx, pmaxy = F(pmaxx + F(wx * BBOX_PADDING)), F(pmaxy + F(wy * BBOX_PADDING))
         self.bbox = (pminx, pminy, pmaxx, pmaxy)
-        # Grid2D::Init (Grid2D.cpp:212-246)
+        # Grid2D::Init (Grid2D.cpp:212-246): physical -> grid coordinates for the points of every frame
         self.dimx = int(math.ceil(float(F(pmaxx - pminx)) / dx)) + 1
         self.dimy = int(math.ceil(float(F(pmaxy - pminy)) / dy)) + 1
         if align:
             self.dimx, self.dimy = align_by_32(self.dimx), align_by_32(self.dimy)
         fdx, fdy = F(dx), F(dy)
-        for sh in fr["shapes"]:
-            sh["gpoints"] = [(F(F(p[0] - pminx) / fdx), F(F(p[1] - pminy) / fdy)) for p in sh["points"]]
-        self.shapes = fr["shapes"]
+        for fr in frames:
+            for sh in fr["shapes"]:
+                sh["gpoints"] = [(F(F(p[0] - pminx) / fdx), F(F(p[1] - pminy) / fdy)) for p in sh["points"]]
+        self.prepare(time)
+
+    # ---- frames in time (Grid2D.cpp:447-519) ---------------------------------------------------------------------
+    def cycle_length(self):
+        return float(sum(fr["duration"] for fr in self.frames))            # GetCycleLenght
+
+    def _locate(self, time):
+        a = [0.0]
+        for fr in self.frames:
+            a.append(a[-1] + fr["duration"])
+        r = math.fmod(time, a[-1])
+        frame = 0
+        for i in range(1, self.num_frames):
+            if a[i] < r:
+                frame = i
+        return frame, r, a
+
+    def get_frame(self, time):
+        return self._locate(time)[0]                                         # GetFrame
+
+    def layer_time(self, time):
+        frame, r, a = self._locate(time)
+        return float(F(a[frame + 1] - r))                                    # GetLayerTime
+
+    def prepare(self, time):
+        """Grid2D::Prepare(time) -> ComputeSubframe(frame, substep) -> Build (Grid2D.cpp:398-461)."""
+        frame, r, a = self._locate(time)
+        sub = (r - a[frame]) / (a[frame + 1] - a[frame])
+        f0, f1 = self.frames[frame], self.frames[(frame + 1) % self.num_frames]
+        s, i_s = F(sub), F(1 - sub)
+        self.shapes = []
+        for sa, sb in zip(f0["shapes"], f1["shapes"]):
+            g = [(F(F(pa[0] * i_s) + F(pb[0] * s)), F(F(pa[1] * i_s) + F(pb[1] * s))) for pa, pb in zip(sa["gpoints"], sb["gpoints"])]
+            v = [(F(F(va[0] * i_s) + F(vb[0] * s)), F(F(va[1] * i_s) + F(vb[1] * s))) for va, vb in zip(sa["vel"], sb["vel"])]
+            self.shapes.append({"gpoints": g, "vel": v, "active": sa["active"]})
         self.build()
 
     def _raster_line(self, p1, p2, v1, v2, color):
@@ -274,8 +318,25 @@ def load_case(data_path, config_path, align=True):
     if cfg.in_fmt != "Shape2D":
         raise NotImplementedError("in_fmt %s: only Shape2D inputs are supported" % cfg.in_fmt)
     nodes, g2 = load_shape2d(data_path, cfg.dx, cfg.dy, cfg.dz, cfg.depth, cfg.depth_var, cfg.baseT, align)
-    dt = g2.duration / (1 * cfg.time_steps)          # length / (frames * time_steps), FluidSolver3D.cpp:194-196
+    cfg.grid2d = g2
+    dt = g2.cycle_length() / (g2.num_frames * cfg.time_steps)          # length / (frames * time_steps), FluidSolver3D.cpp:194-196
     return nodes, cfg, dt
+
+
+def time_loop(g2, cfg, max_steps=-1):
+    """The reference's 3D time loop as data (FluidSolver3D.cpp:193-266): yields (t, i, frame, compute_error, output_layer) per
+    step.  The substep counter i restarts at every frame change; the error is evaluated when i % 10 == 0 or on the last step,
+    a result layer is written when i % out_time_steps == 0."""
+    length = g2.cycle_length()
+    dt = length / (g2.num_frames * cfg.time_steps)
+    finaltime = length * cfg.cycles
+    t, i, last, n = dt, 0, -1, 0
+    while t < finaltime and (max_steps < 0 or n < max_steps):
+        frame = g2.get_frame(t)
+        if frame != last:
+            last, i = frame, 0
+        yield t, i, frame, (i % 10 == 0) or (t + dt >= finaltime), i % cfg.out_time_steps == 0
+        t += dt; i += 1; n += 1
 
 
 def node_in_count(data_path, dx, dy, dz, depth, align=True):

@@ -141,3 +141,61 @@ def test_oracle_is_bit_identical_across_thread_counts(tmp_path):
         subprocess.check_call([sys.executable, "-c", code, path], env=dict(os.environ, OMP_NUM_THREADS=str(nt)))
         outs.append(np.load(path))
     assert np.array_equal(outs[0], outs[1])
+
+
+# ---- multi-frame Shape2D: data/3D/large_tests/heart_us, 10 frames -----------------------------------
+HEART = os.path.join(INP, "heart_us_2D_data.txt")
+HEART_CONF = os.path.join(INP, "heart_us_2D_config.txt")
+
+
+def test_multi_frame_input_loads_all_frames():
+    """Grid2D::LoadFromFile reads every frame; the bounding box (and so the grid) covers the wall's whole motion; the border
+    velocities of frame j+1 are its displacement from frame j over frame j's duration (Grid2D.cpp:375-396)."""
+    f32 = np.float32
+    frames = shape2d.parse_shape2d(open(HEART).read())
+    assert len(frames) == 10 and all(len(fr["shapes"]) == 3 for fr in frames)
+    raw = [[list(sh["points"]) for sh in fr["shapes"]] for fr in frames]
+    dx = float(f32(0.0007))
+    g2 = shape2d.Grid2D(frames, dx, dx, 1.0, True)
+    assert (g2.dimx, g2.dimy) == (96, 160) and g2.num_frames == 10
+    assert abs(g2.cycle_length() - 0.11) < 1e-6
+    xs = [p[0] for fr in raw for sh in fr for p in sh]
+    one = shape2d.Grid2D(shape2d.parse_shape2d(open(HEART).read())[:1], dx, dx, 1.0, False)
+    assert g2.bbox[0] < min(xs) and g2.bbox[2] > max(xs) and (g2.bbox[2] - g2.bbox[0]) > (one.bbox[2] - one.bbox[0])
+    # the wall (shape 0, passive) of frame 0 moves with (P0 - P9) / duration9
+    k = 7
+    want = f32(f32(raw[0][0][k][0] - raw[9][0][k][0]) * f32(1.0 / frames[9]["duration"]))
+    assert frames[0]["shapes"][0]["vel"][k][0] == want and want != 0
+    # time 0 = frame 0 without interpolation: the rasterised wall carries frame 0's velocities
+    assert g2.shapes[0]["gpoints"] == frames[0]["shapes"][0]["gpoints"] and g2.shapes[0]["vel"] == frames[0]["shapes"][0]["vel"]
+    assert np.abs(g2.velx[g2.cell == grids.NODE_BOUND]).max() > 0.1
+
+
+def test_multi_frame_time_functions():
+    """GetFrame / GetLayerTime / Prepare(time) (Grid2D.cpp:447-519): a frame starts strictly after its start time."""
+    dx = float(np.float32(0.0007))
+    g2 = shape2d.Grid2D(shape2d.parse_shape2d(open(HEART).read()), dx, dx, 1.0, True)
+    d = g2.frames[0]["duration"]
+    assert [g2.get_frame(x * d) for x in (0.0, 0.5, 1.0, 1.5, 9.5, 10.5)] == [0, 0, 0, 1, 9, 0]
+    assert abs(g2.layer_time(1.25 * d) - 0.75 * d) < 1e-7
+    a = np.array(g2.frames[3]["shapes"][0]["gpoints"]); b = np.array(g2.frames[4]["shapes"][0]["gpoints"])
+    g2.prepare(3.5 * d)
+    np.testing.assert_allclose(np.array(g2.shapes[0]["gpoints"]), 0.5 * (a + b), rtol=1e-6)
+    cells_mid = g2.cell.copy()
+    g2.prepare(0.0)
+    assert (cells_mid != g2.cell).any()
+
+
+def test_multi_frame_case_and_time_loop():
+    """dt = cycle length / (frames * time_steps); the substep counter restarts with every frame (FluidSolver3D.cpp:193-241)."""
+    nodes, cfg, dt = shape2d.load_case(HEART, HEART_CONF)
+    assert nodes.shape == (96, 160, 128)
+    assert abs(dt - 0.11 / 30) < 1e-8
+    loop = list(shape2d.time_loop(cfg.grid2d, cfg))
+    frames = [fr for _, _, fr, _, _ in loop]
+    assert frames == sorted(frames) and set(frames) == set(range(10))
+    for n, (t, i, fr, with_err, output) in enumerate(loop):
+        if n and frames[n - 1] != fr:
+            assert i == 0 and with_err and output
+    assert loop[-1][3]                                   # the last step evaluates the error
+    assert sum(o for *_, o in loop) >= 19

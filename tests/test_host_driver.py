@@ -23,7 +23,8 @@ def _exact_kernels(monkeypatch):
 HERE = os.path.dirname(os.path.abspath(__file__))
 INPUTS = os.path.join(HERE, "golden", "inputs")
 CASES = {"box_pipe": ("box_pipe_2D_data.txt", "box_pipe_2D_config.txt"),
-         "non_uniform_pipe": ("non_uniform_pipe_2D_data.txt", "non_uniform_pipe_2D_config.txt")}
+         "non_uniform_pipe": ("non_uniform_pipe_2D_data.txt", "non_uniform_pipe_2D_config.txt"),
+         "heart_us": ("heart_us_2D_data.txt", "heart_us_2D_config.txt")}           # 10 frames (moving wall + valve)
 
 
 @pytest.fixture(scope="module")
@@ -133,6 +134,40 @@ def test_driver_runs_the_shipped_example(driver, tmp_path):
         np.testing.assert_array_equal(f.variables["T"][r], T)
     np.testing.assert_allclose(f.variables["time"][:], np.arange(len(layers)) * dt * cfg.out_time_steps)
     f.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [["GPU"], ["GPU", "2", "--same-device"]])
+def test_driver_runs_a_multi_frame_input(driver, mode, tmp_path):
+    """The 10-frame heart_us input: dt = cycle length / (frames * time_steps), the substep counter restarts at every frame
+    (which moves the error evaluation and the output cadence), the geometry stays frame 0's (FluidSolver3D.cpp:193-266).
+    The driver's prints and result layers equal the Python path's, which runs shape2d.time_loop over the same library."""
+    from scipy.io import netcdf_file
+    data, cfgf = (os.path.join(INPUTS, f) for f in CASES["heart_us"])
+    prefix = str(tmp_path / "heart")
+    out = subprocess.run([driver, data, prefix, cfgf, "align"] + mode, check=True, capture_output=True, text=True).stdout
+    nodes, cfg, dt = shape2d.load_case(data, cfgf, align=True)
+    loop = list(shape2d.time_loop(cfg.grid2d, cfg))
+    assert len(loop) in (29, 30) and {fr for _, _, fr, _, _ in loop} == set(range(10))
+    assert [(int(a), int(b)) for a, b in re.findall(r"frame (\d+)\tsubstep (\d+)", out)] == [(fr, i) for _, i, fr, _, _ in loop]
+    s = capi.Solver(nodes, capi.fluid_params(np.float32, cfg.Re, cfg.Pr, cfg.lam), np.float32)
+    layers, ref_err = [], []
+    for t, i, fr, with_err, output in loop:
+        s.UpdateBoundaries()
+        e = s.TimeStep(np.float32(dt), cfg.num_global, cfg.num_local, with_err)
+        ref_err.append(e if with_err else ref_err[-1])
+        if output:
+            layers.append(s.GetLayer((cfg.outdimx, cfg.outdimy, cfg.outdimz)))
+    errs = [float(x) for x in re.findall(r"err = ([0-9.]+),", out)]
+    np.testing.assert_allclose(errs, [float("%.8f" % e) for e in ref_err], atol=1e-12)
+    f = netcdf_file(prefix + "_res.nc", "r", mmap=False)
+    assert f.variables["u"].shape == (len(layers), cfg.outdimx, cfg.outdimy, cfg.outdimz)
+    for r, (V, T) in enumerate(layers):
+        for c, name in enumerate("uvw"):
+            np.testing.assert_array_equal(f.variables[name][r], V[..., c].astype(np.float64))
+        np.testing.assert_array_equal(f.variables["T"][r], T)
+    f.close()
+    assert np.abs(layers[-1][0][layers[-1][0] < 9e4]).max() > 1e-3           # the moving wall drives a flow
 
 
 @pytest.mark.gpu
