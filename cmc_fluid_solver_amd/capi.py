@@ -50,6 +50,7 @@ SYMBOLS = {
     "fs3d_local_group_abort": (None, [_vp]),
     "fs3d_comm_init_local": (_i, [_vp, _vp, _i]),
     "fs3d_comm_abort": (_i, [_vp]),
+    "fs3d_comm_selftest": (_i, [_vp, C.c_size_t]),
     "fs3d_last_step_timing": (_i, [_vp, C.POINTER(C.c_float), C.POINTER(_i)]),
     "fs3d_enable_timing": (_i, [_vp, _i]),
     "fs3d_profiler_events": (_i, [_vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(_i)]),
@@ -138,6 +139,10 @@ class Solver:
     def comm_init(self, unique_id, rank, nranks):
         buf = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
         self._chk(self.lib.fs3d_comm_init(self.h, buf, rank, nranks))
+
+    def comm_selftest(self, elems=1 << 18):
+        """One-rank RCCL communicator on this context's device: grouped send/recv, all-gather, all-reduce, verified."""
+        self._chk(self.lib.fs3d_comm_selftest(self.h, elems))
 
     def comm_abort(self):
         self._chk(self.lib.fs3d_comm_abort(self.h))

@@ -189,6 +189,57 @@ extern "C" fs3d_status fs3d_comm_abort(fs3d_ctx *c)
     return FS3D_OK;
 }
 
+extern "C" fs3d_status fs3d_comm_selftest(fs3d_ctx *c, size_t elems)
+{
+    if (!c || elems == 0 || elems > ((size_t)1 << 28)) return FS3D_ERR_INVALID;
+    if (hipSetDevice(c->device) != hipSuccess) { c->err = "hipSetDevice failed"; return FS3D_ERR_HIP; }
+    ncclUniqueId id;
+    NCCLCHK(c, ncclGetUniqueId(&id));
+    ncclComm_t comm;
+    NCCLCHK(c, ncclCommInitRank(&comm, 1, id, 0));
+    const size_t bytes = elems * c->esize;
+    char *src = nullptr, *dst = nullptr; double *red = nullptr;
+    std::vector<unsigned char> pat(bytes), back(bytes);
+    for (size_t i = 0; i < bytes; i++) pat[i] = (unsigned char)((i * 2654435761u) >> 13);
+    for (size_t i = c->esize - 1; i < bytes; i += c->esize) pat[i] &= 0x3f;          // finite values of either precision
+    fs3d_status st = FS3D_OK;
+    auto hipfail = [&](const char *what) { c->err = std::string("comm selftest: ") + what; st = FS3D_ERR_HIP; };
+    auto ncclfail = [&](const char *what, ncclResult_t r) { st = cfail(c, what, r); };
+    const ncclDataType_t dt = c->prec == FS3D_F32 ? ncclFloat : ncclDouble;
+    hipStream_t s2 = nullptr;                      // a second, non-blocking stream like the one the halo planes travel on
+    do {
+        if (hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess) { s2 = nullptr; hipfail("stream"); break; }
+        if (hipMalloc((void **)&src, bytes) != hipSuccess || hipMalloc((void **)&dst, bytes) != hipSuccess || hipMalloc((void **)&red, 2 * sizeof(double)) != hipSuccess) { hipfail("hipMalloc"); break; }
+        if (hipMemcpy(src, pat.data(), bytes, hipMemcpyHostToDevice) != hipSuccess || hipMemset(dst, 0, bytes) != hipSuccess) { hipfail("upload"); break; }
+        // 1. grouped send/recv (the halo-plane shape), own rank as the peer, on the exchange stream
+        ncclResult_t r;
+        if ((r = ncclGroupStart()) != ncclSuccess) { ncclfail("ncclGroupStart", r); break; }
+        ncclResult_t r1 = ncclSend(src, elems, dt, 0, comm, s2), r2 = ncclRecv(dst, elems, dt, 0, comm, s2);
+        r = ncclGroupEnd();
+        if (r1 != ncclSuccess || r2 != ncclSuccess || r != ncclSuccess) { ncclfail("grouped ncclSend/ncclRecv", r1 != ncclSuccess ? r1 : r2 != ncclSuccess ? r2 : r); break; }
+        if (hipStreamSynchronize(s2) != hipSuccess || hipMemcpy(back.data(), dst, bytes, hipMemcpyDeviceToHost) != hipSuccess) { hipfail("send/recv readback"); break; }
+        if (back != pat) { c->err = "comm selftest: grouped send/recv delivered other bytes than were sent"; st = FS3D_ERR_COMM; break; }
+        // 2. all-gather (the interface words of the cross-slab X solve), on the compute stream
+        if (hipMemset(dst, 0, bytes) != hipSuccess) { hipfail("memset"); break; }
+        if ((r = ncclAllGather(src, dst, elems, dt, comm, c->stream)) != ncclSuccess) { ncclfail("ncclAllGather", r); break; }
+        if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(back.data(), dst, bytes, hipMemcpyDeviceToHost) != hipSuccess) { hipfail("all-gather readback"); break; }
+        if (back != pat) { c->err = "comm selftest: all-gather delivered other bytes than were sent"; st = FS3D_ERR_COMM; break; }
+        // 3. the 2-double all-reduce of EvalDivError, in place
+        const double v[2] = {1.25, 42.0};
+        double w[2] = {0, 0};
+        if (hipMemcpy(red, v, sizeof v, hipMemcpyHostToDevice) != hipSuccess) { hipfail("upload"); break; }
+        if ((r = ncclAllReduce(red, red, 2, ncclDouble, ncclSum, comm, c->stream)) != ncclSuccess) { ncclfail("ncclAllReduce", r); break; }
+        if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(w, red, sizeof w, hipMemcpyDeviceToHost) != hipSuccess) { hipfail("all-reduce readback"); break; }
+        if (w[0] != v[0] || w[1] != v[1]) { c->err = "comm selftest: all-reduce over one rank changed the values"; st = FS3D_ERR_COMM; break; }
+    } while (0);
+    if (src) hipFree(src);
+    if (dst) hipFree(dst);
+    if (red) hipFree(red);
+    if (s2) hipStreamDestroy(s2);
+    if (st == FS3D_OK) ncclCommDestroy(comm); else ncclCommAbort(comm);
+    return st;
+}
+
 void fs3d_comm_destroy(fs3d_ctx *c)
 {
     if (c && c->comm) { ncclCommDestroy((ncclComm_t)c->comm); c->comm = nullptr; }

@@ -186,6 +186,12 @@ fs3d_status fs3d_comm_init_local(fs3d_ctx *ctx, void *group, int rank);
  * main catches and calls MPI_Abort, GPUplan.cpp:173-193, FluidSolver3D.cpp:272-283).  The library calls it itself when a
  * multi-step exchange (the cross-slab X sweep) fails half way. */
 fs3d_status fs3d_comm_abort(fs3d_ctx *ctx);
+/* Wire check on one card: a communicator of ONE rank is created on the context's device and the three RCCL shapes the slab
+ * protocol uses are run and verified -- a grouped ncclSend/ncclRecv pair (the halo-plane / carry-row shape, to the own rank,
+ * on the exchange stream), ncclAllGather (the interface words of the cross-slab X solve) and the 2-double ncclAllReduce of
+ * EvalDivError.  Says whether librccl loads, initialises and moves bytes inside this library (beside the caller's own RCCL);
+ * it does not replace a run on several GPUs.  `elems` elements of the context's precision per message. */
+fs3d_status fs3d_comm_selftest(fs3d_ctx *ctx, size_t elems);
 
 /* ---- measurement ---------------------------------------------------------------
  * Wall time of the kernels of the last fs3d_time_step* call, measured with HIP events
