@@ -146,9 +146,16 @@ __global__ void __launch_bounds__(LT * NCH, WPS) k_sweep_part(SweepParams<R> p, 
     R *const ldsD = (R *)part_smem;                      // [NCH*M][LT]  dT of every cell (P -> E)
     R *const ex = ldsD + NCH * M * LT;                  // [PART_EXW][NCH][LT]
     const int t = threadIdx.x, kk = t % LT, ch = t / LT;
-    // measurement only (fs3d_profile_sweep): 8 s_memtime stamps per wave
+    // measurement only (fs3d_profile_sweep): 8 s_memtime stamps per wave; wave 7 stamps the constant-rate, chip-wide
+    // s_memrealtime (100 MHz) instead -- s_memtime counters are not aligned between CUs
     unsigned long long *const stamp = p.stamps ? p.stamps + ((size_t)blockIdx.x * 8 + (t >> 6) % 8) * 8 : nullptr;
-#define PSTAMP(k) do { if (stamp && (t & 63) == 0 && (t >> 6) < 8) stamp[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#define PSTAMP(k) do { if (stamp && (t & 63) == 0 && (t >> 6) < 8) stamp[k] = (t >> 6) == 7 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); } while (0)
+    // Start stagger: the first workgroup of every CU starts with the launch, so all CUs load, then solve, then store at the
+    // same time and HBM idles while they solve (tools/part_phases.py timeline).  Part of the first generation starts late.
+    if ((order & 0x30) && blockIdx.x < 256) {
+        const int grp = (order & 0x20) ? (int)((blockIdx.x >> 3) % 3) : (int)((blockIdx.x >> 3) & 1);
+        for (int w = grp * (order >> 8); w > 0; w--) __builtin_amdgcn_s_sleep(127);
+    }
     PSTAMP(0);
 
     // XCD-aware block order (speed only): blocks b, b+8, .. share an XCD under round-robin dispatch; give each XCD a
