@@ -620,29 +620,40 @@ __device__ __forceinline__ void pst4(prsrc_t r, unsigned vo, unsigned so, const 
     asm volatile("s_nop 1" : : "v"(q.x), "v"(q.y), "v"(q.z), "v"(q.w));
 }
 
-struct ZLine { PV4 tc[4], cu[4], wim, wip, wjm, wjp; pu32x2 code; float nve[4]; };   // wjm/wjp: only where a wave-wide access holds several lines
+struct ZLine { PV4 tc[4], cu[4], wim, wip, wjm, wjp; pu32x2 code; float nve[4], nb[4]; };   // wjm/wjp: only where a wave-wide access holds several lines; nb: NW == 2
 
-template <int LPL, int WPS>
+// NW == 2 (lines of 260..512 cells): a line is held by a PAIR of waves (waves 2q, 2q+1 of the workgroup: cells [0,256) and
+// [256,512)).  Each wave reduces its 64 interface unknowns by itself; the single coupling between the halves (the row of the
+// lower wave's last lane <-> the upper wave's first unknown) is carried through the cyclic reduction as one more right-hand
+// side per matrix, and a 2x2 system per right-hand side joins the halves (two small LDS exchanges + barriers per line).
+template <int LPL, int WPS, int NW = 1>
 __global__ void __launch_bounds__(256, WPS) k_sweep_part_z(SweepParams<float> p, int n_grp, int LG)
 {
     typedef float R;
+    static_assert(NW == 1 || (NW == 2 && LPL == 64), "a pair of waves per line: 64 lanes each");
     constexpr int LI = 64 / LPL;                        // lines per wave-wide access
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l = lane % LPL, sub = lane / LPL;
+    const int hi = NW == 2 ? (w & 1) : 0;               // upper half of the line
+    const int gl = l + 64 * hi;                         // position of this lane's piece along the line
+    __shared__ float zx1[2][8], zx2[2][2][8];           // NW == 2: [pair][..] exchange buffers
     int lb = blockIdx.x;
     {
         const int nb = gridDim.x, q = nb >> 3, r = nb & 7, x = lb & 7, slot = lb >> 3;
         lb = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + slot;
     }
     // task = (group of LG*LI lines, plane): consecutive tasks = consecutive planes of one line group
-    const int task = lb * 4 + w;
+    const int task = NW == 2 ? lb * 2 + (w >> 1) : lb * 4 + w;
     const int npl = p.o_count ? p.o_count : p.dimx;    // planes of this launch
-    const int grp = task / npl, i = task - grp * npl + p.o_begin;
-    if (grp >= n_grp) return;                           // whole wave (wave-uniform)
+    int grp = task / npl;
+    const int i = task - grp * npl + p.o_begin;
+    bool task_ok = true;
+    if (NW == 1) { if (grp >= n_grp) return; }          // whole wave (wave-uniform)
+    else { task_ok = grp < n_grp; grp = task_ok ? grp : n_grp - 1; }   // the pairs of a workgroup meet at barriers: a pair past the end runs along, stores nothing
     const int n = p.dimz;
     const int j0 = grp * LG * LI;
-    const bool l_ok = 4 * l < n;
-    const int lc = l_ok ? l : (n / 4 - 1);
+    const bool l_ok = 4 * gl < n;
+    const int lc = l_ok ? gl : (n / 4 - 1);
     const unsigned fsb = (unsigned)(p.fstride * 4ll), nsb = (unsigned)(p.nstride * 4ll);
     const unsigned rowb = (unsigned)p.dimz * 4u, planeb = (unsigned)(p.plane * 4ll);
     const unsigned lbytes = 4u * fsb;
@@ -663,9 +674,13 @@ __global__ void __launch_bounds__(256, WPS) k_sweep_part_z(SweepParams<float> p,
     const unsigned vo_l = (unsigned)(sub * p.dimz + 4 * lc) * 4u;          // per-lane bytes: own line of the row, own piece
     // the two lanes that hold the ends of the line (cell 0: START or SKIP; cell n-1: END or SKIP) fetch that cell's node
     // values with the line's other loads: every line has them, they must not cost a memory round trip of their own
-    const bool is_end = l_ok && (l == 0 || l == n / 4 - 1);
-    const int ec = l == 0 ? 0 : 3;
+    const bool is_end = l_ok && (gl == 0 || gl == n / 4 - 1);
+    const int ec = gl == 0 ? 0 : 3;
     const unsigned vo_e = is_end ? vo_l + 4u * (unsigned)ec : PART_OOB;
+    // NW == 2: the cell across the cut between the two waves (cell 255 for the upper wave's first lane, 256 for the lower
+    // wave's last lane) comes with the line's other loads
+    const bool at_cut = NW == 2 && (hi ? l == 0 : l == 63);
+    const unsigned vo_nb = at_cut ? (hi ? 255u * 4u : 256u * 4u) : PART_OOB;
 
     auto issue = [&](int jrow, ZLine &L) __attribute__((always_inline)) {
         // jrow: first line of the row (wave-uniform); this lane's line is jrow + sub, clamped into the plane for the loads
@@ -681,12 +696,16 @@ __global__ void __launch_bounds__(256, WPS) k_sweep_part_z(SweepParams<float> p,
         L.code = __builtin_amdgcn_raw_buffer_load_b64(rCode, vo_l / 2u, son / 2u, 0);
 #pragma unroll
         for (int f = 0; f < 4; f++) L.nve[f] = PBuf<R>::ld(rNode, vo_e, son + (unsigned)f * nsb);     // other lanes: out of range, no memory access
+        if (NW == 2) {
+#pragma unroll
+            for (int f = 0; f < 4; f++) L.nb[f] = PBuf<R>::ld(Ltmp, vo_nb, so + (unsigned)f * fsb);
+        }
     };
 
     // wjm / wjp: W of the lines j-1 / j+1 (LI == 1: the neighbouring rows' registers; else loaded with the line)
     auto process = [&](int jrow, const ZLine &L, const PV4 &wjm, const PV4 &wjp) __attribute__((always_inline)) {
         const int j = jrow + sub;
-        const bool st_ok = l_ok && j < p.dimy;           // lines past the plane compute on whatever was loaded, nothing is stored
+        const bool st_ok = l_ok && j < p.dimy && task_ok; // lines past the plane compute on whatever was loaded, nothing is stored
         const unsigned so = opq_s(line_so(jrow)), son = opq_s(line_son(jrow));
         // ---- codes
         int code4[4]; bool isin[4], seg[4], inter[4];
@@ -704,7 +723,10 @@ __global__ void __launch_bounds__(256, WPS) k_sweep_part_z(SweepParams<float> p,
         // ---- rows: neighbours along the line from the lanes next door
         R tm1[4], tp4[4];                                 // cell 4l-1 and cell 4l+4 of U, V, W, T
 #pragma unroll
-        for (int f = 0; f < 4; f++) { tm1[f] = __shfl_up(L.tc[f].v[3], 1, LPL); tp4[f] = __shfl_down(L.tc[f].v[0], 1, LPL); }
+        for (int f = 0; f < 4; f++) {
+            tm1[f] = __shfl_up(L.tc[f].v[3], 1, LPL); tp4[f] = __shfl_down(L.tc[f].v[0], 1, LPL);
+            if (NW == 2) { tm1[f] = (at_cut && hi) ? L.nb[f] : tm1[f]; tp4[f] = (at_cut && !hi) ? L.nb[f] : tp4[f]; }
+        }
         R q[4], d[4][4];                                  // d[f][c]
 #pragma unroll
         for (int c = 0; c < 4; c++) {
@@ -773,9 +795,16 @@ __global__ void __launch_bounds__(256, WPS) k_sweep_part_z(SweepParams<float> p,
         // ---- interface row (cell 3) with x[2] eliminated and x_first of the next lane substituted; normalised
         R av, cv_, at, ct_, dd[4];
         {
-            const R nvf = __shfl_down(apv, 1, LPL), nwf = __shfl_down(upv, 1, LPL), ntf = __shfl_down(apt, 1, LPL), nuf = __shfl_down(upt, 1, LPL);
-            const R ng0 = __shfl_down(ep3[0], 1, LPL), ng1 = __shfl_down(ep3[1], 1, LPL), ng2 = __shfl_down(ep3[2], 1, LPL), ng3 = __shfl_down(ep1[0], 1, LPL);
-            const bool last = l == LPL - 1;                // no lane behind: its first cell does not exist (the row has c = 0 anyway)
+            R nvf = __shfl_down(apv, 1, LPL), nwf = __shfl_down(upv, 1, LPL), ntf = __shfl_down(apt, 1, LPL), nuf = __shfl_down(upt, 1, LPL);
+            R ng0 = __shfl_down(ep3[0], 1, LPL), ng1 = __shfl_down(ep3[1], 1, LPL), ng2 = __shfl_down(ep3[2], 1, LPL), ng3 = __shfl_down(ep1[0], 1, LPL);
+            if (NW == 2) {
+                // the lower wave's last lane takes the up-sweep of the upper wave's first lane
+                float *const b = zx1[w >> 1];
+                if (hi && l == 0) { b[0] = apv; b[1] = upv; b[2] = apt; b[3] = upt; b[4] = ep3[0]; b[5] = ep3[1]; b[6] = ep3[2]; b[7] = ep1[0]; }
+                __syncthreads();
+                if (at_cut && !hi) { nvf = b[0]; nwf = b[1]; ntf = b[2]; nuf = b[3]; ng0 = b[4]; ng1 = b[5]; ng2 = b[6]; ng3 = b[7]; }
+            }
+            const bool last = NW == 2 ? (hi && l == 63) : l == LPL - 1;   // no lane behind: its first cell does not exist (the row has c = 0 anyway)
             const R clv = last ? R(0) : mv[3].c, clt = last ? R(0) : mt[3].c;
             const R lov = -mv[3].a * lpv[2], div = pfma(-clv, nvf, pfma(-mv[3].a, cpv[2], mv[3].b)), upv_ = -clv * nwf;
             const R lot = -mt[3].a * lpt[2], dit = pfma(-clt, ntf, pfma(-mt[3].a, cpt[2], mt[3].b)), upt_ = -clt * nuf;
@@ -785,6 +814,13 @@ __global__ void __launch_bounds__(256, WPS) k_sweep_part_z(SweepParams<float> p,
             dd[1] = pquot(pfma(-clv, ng1, pfma(-mv[3].a, dpd[2][1], d[1][3])), div, rv);
             dd[2] = pquot(pfma(-clv, ng2, pfma(-mv[3].a, dpd[2][2], d[2][3])), div, rv);
             dd[3] = pquot(pfma(-clt, ng3, pfma(-mt[3].a, dpd[2][3], d[3][3])), dit, rt);
+        }
+        // NW == 2: the coupling across the cut leaves the wave's system and becomes a right-hand side of its own
+        // (x_l = X_l - Z * E_l with Z the unknown on the other side of the cut)
+        R ev = R(0), et = R(0);
+        if (NW == 2) {
+            if (at_cut && !hi) { ev = cv_; et = ct_; cv_ = R(0); ct_ = R(0); }
+            if (at_cut && hi) { ev = av; et = at; av = R(0); at = R(0); }
         }
         // ---- parallel cyclic reduction over the LPL lanes of the line
 #pragma unroll
@@ -802,15 +838,37 @@ __global__ void __launch_bounds__(256, WPS) k_sweep_part_z(SweepParams<float> p,
 #pragma unroll
             for (int k = 0; k < 3; k++) dd[k] = pquot(pfma(-a_v, dm[k], pfma(-c_v, dq[k], dd[k])), dnv, rv);
             dd[3] = pquot(pfma(-a_t, dm[3], pfma(-c_t, dq[3], dd[3])), dnt, rt);
+            if (NW == 2) {
+                const R emv = __shfl_up(ev, s, LPL), eqv = __shfl_down(ev, s, LPL), emt = __shfl_up(et, s, LPL), eqt = __shfl_down(et, s, LPL);
+                ev = pquot(pfma(-a_v, emv, pfma(-c_v, eqv, ev)), dnv, rv);
+                et = pquot(pfma(-a_t, emt, pfma(-c_t, eqt, et)), dnt, rt);
+            }
             av = pquot(-a_v * amv, dnv, rv); cv_ = pquot(-c_v * cpv_, dnv, rv);
             at = pquot(-a_t * amt, dnt, rt); ct_ = pquot(-c_t * cpt_, dnt, rt);
         }
         // ---- back-substitution: x[3] = X, x[c] = d'[c] - l[c] X_left - c'[c] x[c+1]
         R x[4][4];                                        // x[f][c]
         {
+            R xcut[4] = {R(0), R(0), R(0), R(0)};         // NW == 2, upper wave: the lower wave's last unknown
+            if (NW == 2) {
+                // join the halves: X = Xd - Y0 E_lo, Y = Yd - X63 E_hi  ->  per right-hand side a 2x2 system in (X63, Y0)
+                float *const bl = zx2[w >> 1][0], *const bh = zx2[w >> 1][1];
+                if (at_cut) { float *const b = hi ? bh : bl; b[0] = dd[0]; b[1] = dd[1]; b[2] = dd[2]; b[3] = dd[3]; b[4] = ev; b[5] = et; }
+                __syncthreads();
+                const R elv = bl[4], elt = bl[5], ehv = bh[4], eht = bh[5];
+                const R rdv = prcp(pfma(-elv, ehv, R(1))), rdt = prcp(pfma(-elt, eht, R(1)));
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const R el = k < 3 ? elv : elt, eh = k < 3 ? ehv : eht, den = pfma(-el, eh, R(1));
+                    const R x63 = pquot(pfma(-el, bh[k], bl[k]), den, k < 3 ? rdv : rdt);
+                    const R y0 = pfma(-x63, eh, bh[k]);
+                    dd[k] = pfma(-(hi ? x63 : y0), k < 3 ? ev : et, dd[k]);
+                    xcut[k] = x63;
+                }
+            }
             R xl[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) { xl[k] = __shfl_up(dd[k], 1, LPL); xl[k] = l == 0 ? R(0) : xl[k]; x[k][3] = dd[k]; }
+            for (int k = 0; k < 4; k++) { xl[k] = __shfl_up(dd[k], 1, LPL); xl[k] = l == 0 ? (NW == 2 && hi ? xcut[k] : R(0)) : xl[k]; x[k][3] = dd[k]; }
 #pragma unroll
             for (int c = 2; c >= 0; c--) {
 #pragma unroll
@@ -910,7 +968,7 @@ __global__ void __launch_bounds__(256, WPS) k_sweep_part_z(SweepParams<float> p,
     }
 }
 
-template <int LPL>
+template <int LPL, int NW = 1>
 static bool part_launch_z(fs3d_ctx *c, const SweepParams<float> &p)
 {
     constexpr int LI = 64 / LPL;
@@ -925,7 +983,8 @@ static bool part_launch_z(fs3d_ctx *c, const SweepParams<float> &p)
     const int n_grp = (rows + LG - 1) / LG;
     const long long tasks = (long long)n_grp * (p.o_count ? p.o_count : p.dimx);
     // 2 waves per SIMD: the kernel needs ~200 VGPRs (at 168 it spills 70 of them and runs 1.5x slower)
-    hipLaunchKernelGGL((k_sweep_part_z<LPL, 2>), dim3((unsigned)((tasks + 3) / 4)), dim3(256), 0, c->stream, p, n_grp, LG);
+    if (NW == 2) hipLaunchKernelGGL((k_sweep_part_z<LPL, 2, NW>), dim3((unsigned)((tasks + 1) / 2)), dim3(256), 0, c->stream, p, n_grp, LG);
+    else hipLaunchKernelGGL((k_sweep_part_z<LPL, 2, NW>), dim3((unsigned)((tasks + 3) / 4)), dim3(256), 0, c->stream, p, n_grp, LG);
     return true;
 }
 
@@ -937,6 +996,7 @@ static bool part_dispatch_z(fs3d_ctx *c, const SweepParams<float> &p)
     if (n <= 64) return part_launch_z<16>(c, p);
     if (n <= 128) return part_launch_z<32>(c, p);
     if (n <= 256) return part_launch_z<64>(c, p);
+    if (n <= 512) return part_launch_z<64, 2>(c, p);       // a pair of waves per line
     return false;
 }
 static bool part_dispatch_z(fs3d_ctx *, const SweepParams<double> &) { return false; }

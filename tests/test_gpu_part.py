@@ -97,6 +97,9 @@ GRIDS = {
     "obstacle_12x256x40": lambda: grids.box_with_obstacle(12, 256, 40, h=0.004),     # full-length Y lines
     "obstacle_10x20x256": lambda: grids.box_with_obstacle(10, 20, 256, h=0.004),     # full-length Z lines (64 lanes per line)
     "obstacle_9x7x128": lambda: grids.box_with_obstacle(9, 7, 128, h=0.01),          # two lines per wave-wide access, odd line count
+    "obstacle_6x9x512": lambda: grids.box_with_obstacle(6, 9, 512, h=0.002),         # Z lines held by a pair of waves, full length
+    "obstacle_8x10x388": lambda: grids.box_with_obstacle(8, 10, 388, h=0.003),       # pair of waves, the upper one partly past the line
+    "box_7x6x260": lambda: grids.box(7, 6, 260, h=0.004),                            # pair of waves, one piece in the upper one
 }
 
 
