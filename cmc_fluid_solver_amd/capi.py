@@ -212,7 +212,7 @@ class Solver:
             k, sg = C.c_int(0), C.c_int(0)
             self._chk(self.lib.fs3d_last_sweep_kernel(self.h, d, C.byref(k), C.byref(sg)))
             out[nm] = KERNEL_NAMES.get(k.value, str(k.value)) + ("-segmented" if sg.value & 1 else "") + \
-                {0: "", 1: "+pipelined-ranks", 2: "+reduced-interface"}[(sg.value >> 1) & 3]
+                {0: "", 1: "+pipelined-ranks", 2: "+reduced-interface", 3: "+reduced-interface(on-chip)"}[(sg.value >> 1) & 3]
         return out
 
     def profiler_events(self):

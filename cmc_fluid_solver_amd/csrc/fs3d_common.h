@@ -63,6 +63,7 @@ struct SweepParams {
     int o_begin, o_count;       // partition kernels: only the planes [o_begin, o_begin + o_count) of the slab (Y and Z sweeps; o_count 0: all) --
                                 // interior planes run beside the halo exchange, the two edge planes after it
     int *errw;                  // device-visible error word (pinned host memory): bit 0 = a relay hand-over of the pipe kernel timed out
+    int xiface_pass;            // X partition kernel on an x-slab: 1 = first pass, the slab's 18 interface words per line -> carry_out (pitch carry_pitch)
     int test_drop;              // test hook (env FS3D_TEST_DROP_HANDOFF): one wave never signals its hand-over; the poll bound is short
     int store_next;             // pipe kernel, fused time step: 0 when a later local iteration overwrites `next` unread (only the merge uses x)
 };
@@ -131,7 +132,7 @@ struct fs3d_ctx {
     int rank = 0, nranks = 1;
     void *xif_send = nullptr, *xif_all = nullptr;   // reduced-interface X sweep: this slab's 18 words per line / all ranks'
     int opt_xsolve = 0;            // FS3D_OPT_XSOLVE: 0 auto, 1 pipelined (bit-exact), 2 reduced interface
-    int ran_xsolve = 0;            // what the last cross-slab X sweep ran: 1 pipelined, 2 reduced interface
+    int ran_xsolve = 0;            // what the last cross-slab X sweep ran: 1 pipelined, 2 reduced interface, 3 reduced interface with the interface words from the partition kernel
     int xblocks = 4;               // line blocks of the cross-slab X sweep pipeline (env FS3D_XBLOCKS)
     std::string err;
 };

@@ -565,6 +565,7 @@ static void fill_params(fs3d_ctx *c, SweepParams<R> &p, int dir, double dt_, int
     p.errw = c->errw_dev;
     p.o_begin = 0; p.o_count = 0;
     { const char *e = getenv("FS3D_TEST_DROP_HANDOFF"); p.test_drop = (e && atoi(e)) ? 1 : 0; }
+    p.xiface_pass = 0;
     p.carry_in = nullptr; p.carry_out = nullptr; p.xcarry_in = nullptr; p.xcarry_out = nullptr; p.bundle0 = 0;
     p.seg_begin = 0; p.seg_len = 0; p.carry_pitch = c->plane; p.seg_index = 0; p.scr_bundles = 0;
     p.ghost_lo = c->x_offset > 0; p.ghost_hi = c->x_offset + c->dimx < c->dimx_global;
@@ -650,12 +651,20 @@ static fs3d_status xsweep_reduced(fs3d_ctx *c, SweepParams<R> &p)
         HIPCHK(c, hipMalloc(&c->xif_all, (size_t)c->nranks * 18 * pl * c->esize));
     }
     struct AbortOnError { fs3d_ctx *c; fs3d_status *st; ~AbortOnError() { if (*st != FS3D_OK) fs3d_comm_abort(c); } } guard{c, &st};
-    launch_xiface<R>(c, p, c->xif_send);
+    // the slab's interface words: a first pass of the X partition kernel (rows and chunk elimination on chip, 8 words per cell
+    // read, 18 words per line written) where it applies, else the thread-per-line walk over the planes
+    bool iface_done = false;
+    if (c->opt_kernel == FS3D_SWEEP_AUTO || c->opt_kernel == FS3D_SWEEP_PART) {
+        SweepParams<R> pa = p;
+        pa.xiface_pass = 1; pa.carry_in = nullptr; pa.xcarry_in = nullptr; pa.carry_out = (R *)c->xif_send; pa.merge = 0; pa.store_next = 0;
+        iface_done = launch_sweep_part<R>(c, 0, pa);
+    }
+    if (!iface_done) launch_xiface<R>(c, p, c->xif_send);
     if ((st = fs3d_comm_allgather(c, c->xif_send, c->xif_all, 18 * pl))) return st;
     launch_xreduce<R>(c, c->xif_all, (long long)pl, c->nranks, c->rank, c->carry[0], c->carry[2]);
     p.carry_in = (const R *)c->carry[0]; p.carry_out = (R *)c->carry[1];
     p.xcarry_in = (const R *)c->carry[2]; p.xcarry_out = (R *)c->carry[3];
-    c->ran_xsolve = 2;
+    c->ran_xsolve = iface_done ? 3 : 2;
     // the slab with both boundary values given: the X partition kernel (rows on chip, 16 words per cell) where it applies ...
     if ((c->opt_kernel == FS3D_SWEEP_AUTO || c->opt_kernel == FS3D_SWEEP_PART) && launch_sweep_part<R>(c, 0, p)) {
         c->ran_kernel[0] = FS3D_SWEEP_PART; c->ran_segmented[0] = 0;
@@ -737,7 +746,9 @@ static fs3d_status sweep_buffers(fs3d_ctx *c, int dir, double dt, int b_cur, int
         if (so) return so;
     }
     rec_begin(c, cls);
-    if (dir == 0 && c->nranks > 1) {
+    // (a slab context without peers that asks for the reduced form runs its kernels on the slab alone: tools/slab_cost.py times
+    // what one rank computes)
+    if (dir == 0 && (c->nranks > 1 || (c->opt_xsolve == 2 && (p.ghost_lo || p.ghost_hi)))) {
         // reduced-interface form (all ranks at once) unless bit-equality with the sequential recurrence was asked for
         const bool reduced = c->opt_xsolve == 2 || (c->opt_xsolve == 0 && (c->opt_kernel == FS3D_SWEEP_AUTO || c->opt_kernel == FS3D_SWEEP_PART));
         fs3d_status st = reduced ? xsweep_reduced<R>(c, p) : xsweep_multi<R>(c, p);

@@ -137,7 +137,7 @@ __device__ __forceinline__ void part_step(R lead, R diag, R trail, R &cp, R &sp,
 #endif
 #define PART_EXW 18               // interface words per (line, chunk): 5 per matrix, 2 per right-hand side
 
-template <typename R, int DIR, int M, int NCH, int WPS, int LT, int PF = FS3D_PART_PF, bool XB = false, int OPF = FS3D_PART_OPF, bool KT = false>
+template <typename R, int DIR, int M, int NCH, int WPS, int LT, int PF = FS3D_PART_PF, int XB = 0, int OPF = FS3D_PART_OPF, bool KT = false>
 __global__ void __launch_bounds__(LT * NCH, WPS) k_sweep_part(SweepParams<R> p, int n_o, int n_tiles, int order)
 {
     static_assert(DIR == 0 || DIR == 1, "lanes along k: X and Y sweeps");
@@ -272,7 +272,10 @@ __global__ void __launch_bounds__(LT * NCH, WPS) k_sweep_part(SweepParams<R> p, 
     const bool dead = p.dead[(long long)o * p.dimz + kc] != 0;
     // X sweep of an x-slab (reduced-interface form, fs3d_hip.hip: xsweep_reduced): the values just below / above the slab on
     // this line are given -- x[-1] in p.carry_in rows 2..5, x[n] in p.xcarry_in rows 0..3 ([value][line], line = j*dimz + k)
-    constexpr bool xb = XB && DIR == 0;                  // a template parameter: the single-GPU instance must not pay registers for it
+    constexpr bool xb = XB == 1 && DIR == 0;             // a template parameter: the single-GPU instance must not pay registers for it
+    // XB == 2: first pass of that sweep -- rows and chunk elimination as always, then the slab's 18 interface words per line
+    // (the layout of k_xiface, kernels_line.hip) to p.carry_out, and nothing else: no boundary values are known yet
+    constexpr bool xa = XB == 2 && DIR == 0;
     // this lane's line in the carry arrays, recomputed where it is needed (a register kept across the kernel costs spills)
     auto cline_of = [&]() __attribute__((always_inline)) {
         const unsigned kc_ = opq_v(vo) / (unsigned)sizeof(R) - (unsigned)((long long)(opq_v(t) / LT * M) * ss);
@@ -391,6 +394,55 @@ __global__ void __launch_bounds__(LT * NCH, WPS) k_sweep_part(SweepParams<R> p, 
     PSTAMP(3);
     __syncthreads();
     PSTAMP(4);
+
+    if constexpr (xa) {
+        // ---- R (first pass of a slab sweep): the chunks' interface rows -> the SLAB's interface row and first cell.
+        // Chunks 0..cA hold the slab (n is a multiple of M: the slab's last plane is the interface cell of chunk cA).
+        //   forward over the chunks:  X_c = dq - lq X_below - cq X_{c+1};  the row of chunk cA then reads
+        //                             (-lo lq) X_below + (Bp - lo cq) X_cA + cl x_first(slab above) = Dp - lo dq
+        //   backward over the chunks: X_c = eq - aq X_{c-1} - uq X_cA;  x_first = Gf0 - Vf0 X_below - Wf0 X_0
+        if (t < 4 * LT) {
+            constexpr int ES = NCH * LT;
+            const int sys = t / LT, cA = n / M - 1;
+            const R *const em = ex + (sys == 3 ? 5 * ES : 0) + kk;
+            const R *const er = ex + (10 + sys) * ES + kk;
+            auto row = [&](int c, R &lo, R &di, R &up, R &rhs) __attribute__((always_inline)) {
+                lo = em[0 * ES + c * LT];
+                const R bp = em[1 * ES + c * LT], cl = em[2 * ES + c * LT];
+                const R vf = em[3 * ES + (c + 1) * LT], wf = em[4 * ES + (c + 1) * LT], gf = er[4 * ES + (c + 1) * LT];
+                di = pfma(-cl, vf, bp); up = -cl * wf; rhs = pfma(-cl, gf, er[c * LT]);
+            };
+            R cq = R(0), dq = R(0), lq = R(-1);
+#pragma nounroll
+            for (int c = 0; c < cA; c++) {
+                R lo, di, up, rhs;
+                row(c, lo, di, up, rhs);
+                const R den = pfma(-lo, cq, di), r = prcp(den);
+                cq = pquot(up, den, r); dq = pquot(pfma(-lo, dq, rhs), den, r); lq = pquot(-lo * lq, den, r);
+            }
+            R eq = R(0), aq = R(0), uq = R(-1);
+#pragma nounroll
+            for (int c = cA - 1; c >= 0; c--) {
+                R lo, di, up, rhs;
+                row(c, lo, di, up, rhs);
+                const R den = pfma(-up, aq, di), r = prcp(den);
+                eq = pquot(pfma(-up, eq, rhs), den, r); uq = pquot(-up * uq, den, r); aq = pquot(lo, den, r);
+            }
+            const R lo = em[0 * ES + cA * LT], bp = em[1 * ES + cA * LT], cl = em[2 * ES + cA * LT];
+            const R vf0 = em[3 * ES], wf0 = em[4 * ES], gf0 = er[4 * ES];
+            // dead lines (no cell of theirs is ever stored) hand over identity words: whatever ran through their lanes stays there
+            R *const o = p.carry_out + cline_of();
+            const long long nl = p.carry_pitch;
+            if (sys == 0 || sys == 3) {
+                const int m = sys == 3 ? 5 : 0;
+                o[(m + 0) * nl] = dead ? R(0) : -lo * lq; o[(m + 1) * nl] = dead ? R(1) : pfma(-lo, cq, bp); o[(m + 2) * nl] = dead ? R(0) : cl;
+                o[(m + 3) * nl] = dead ? R(0) : pfma(-wf0, aq, vf0); o[(m + 4) * nl] = dead ? R(0) : -wf0 * uq;
+            }
+            o[(10 + sys) * nl] = dead ? R(0) : pfma(-lo, dq, er[cA * LT]);
+            o[(14 + sys) * nl] = dead ? R(0) : pfma(-wf0, eq, gf0);
+        }
+        return;
+    }
 
     // ---- R: interface systems, one thread per (line, right-hand side) ----------------------------------------
     if (t < 4 * LT) {
@@ -534,7 +586,7 @@ __global__ void __launch_bounds__(LT * NCH, WPS) k_sweep_part(SweepParams<R> p, 
 #undef PSTAMP
 }
 
-template <typename R, int DIR, int M, int NCH, int WPS, int LT, int PF = FS3D_PART_PF, bool XB = false, int OPF = FS3D_PART_OPF, bool KT = false>
+template <typename R, int DIR, int M, int NCH, int WPS, int LT, int PF = FS3D_PART_PF, int XB = 0, int OPF = FS3D_PART_OPF, bool KT = false>
 static bool part_launch_xy(fs3d_ctx *c, const SweepParams<R> &p)
 {
     const int n_o = DIR == 0 ? p.dimy : (p.o_count ? p.o_count : p.dimx);
@@ -549,7 +601,10 @@ static bool part_launch_xy(fs3d_ctx *c, const SweepParams<R> &p)
         }
         attr_set.fetch_or(dev_bit);
     }
-    static const int order = getenv("FS3D_PART_ORDER") ? atoi(getenv("FS3D_PART_ORDER")) : 0;   // kernel experiments
+    // workgroup order: 32-line tiles run the lane tiles of one row/plane on consecutive workgroups (the 128-byte pieces of a
+    // row are then fetched together: 512^3 X 2.93 -> 2.71 ms, Y 2.18 -> 2.10), 64-line tiles the rows/planes of one lane tile
+    static const int order_env = getenv("FS3D_PART_ORDER") ? atoi(getenv("FS3D_PART_ORDER")) : -1;   // kernel experiments
+    const int order = order_env >= 0 ? order_env : (LT == 32 ? 1 : 0);
     hipLaunchKernelGGL((k_sweep_part<R, DIR, M, NCH, WPS, LT, PF, XB, OPF, KT>), dim3((unsigned)(n_o * n_tiles)), dim3(LT * NCH), lds, c->stream, p, n_o, n_tiles, order);
     return true;
 }
@@ -561,12 +616,26 @@ static bool part_dispatch_xy(fs3d_ctx *c, const SweepParams<R> &p)
     if (n < 4) return false;
     if constexpr (std::is_same<R, float>::value) {       // fp64 contexts run the exact kernels
         static const int variant = getenv("FS3D_PART_VARIANT") ? atoi(getenv("FS3D_PART_VARIANT")) : 0;   // kernel experiments
+        if (DIR == 0 && p.xiface_pass) {
+            // first pass of the cross-slab sweep: the slab's interface words (whole chunks only)
+            constexpr int D0 = 0;
+            if (!p.carry_out) return false;
+            if (n <= 32 && n % 8 == 0) return part_launch_xy<R, D0, 8, 4, 4, 64, FS3D_PART_PF, 2>(c, p);   // thin slabs: 8-cell chunks, every thread has cells
+            if (n % 16 != 0) return false;
+            const bool wide = (long long)p.dimy * ((p.dimz + 63) / 64) >= 512;      // enough 64-line tiles to fill the chip: 256-byte row pieces
+            if (n <= 64) return wide ? part_launch_xy<R, D0, 16, 4, 4, 64, FS3D_PART_PF, 2>(c, p) : part_launch_xy<R, D0, 16, 4, 4, 32, FS3D_PART_PF, 2>(c, p);
+            if (n <= 128) return wide ? part_launch_xy<R, D0, 16, 8, 4, 64, FS3D_PART_PF, 2>(c, p) : part_launch_xy<R, D0, 16, 8, 4, 32, FS3D_PART_PF, 2>(c, p);
+            if (n <= 256) return part_launch_xy<R, D0, 16, 16, 4, 64, FS3D_PART_PF, 2>(c, p);
+            return false;
+        }
         if (DIR == 0 && p.carry_in && p.xcarry_in) {
             // x-slab with the values below / above it given (reduced-interface form of the cross-slab sweep)
             constexpr int D0 = 0;
-            if (n <= 64) return part_launch_xy<R, D0, 16, 4, 4, 32, FS3D_PART_PF, true>(c, p);
-            if (n <= 128) return part_launch_xy<R, D0, 16, 8, 4, 32, FS3D_PART_PF, true>(c, p);
-            if (n <= 256) return part_launch_xy<R, D0, 16, 16, 4, 64, FS3D_PART_PF, true>(c, p);
+            if (n <= 32) return part_launch_xy<R, D0, 8, 4, 4, 64, FS3D_PART_PF, 1>(c, p);      // thin slabs (a 32-plane slab of the 256^3 box)
+            const bool wide = (long long)p.dimy * ((p.dimz + 63) / 64) >= 512;      // enough 64-line tiles to fill the chip: 256-byte row pieces
+            if (n <= 64) return wide ? part_launch_xy<R, D0, 16, 4, 4, 64, FS3D_PART_PF, 1>(c, p) : part_launch_xy<R, D0, 16, 4, 4, 32, FS3D_PART_PF, 1>(c, p);
+            if (n <= 128) return wide ? part_launch_xy<R, D0, 16, 8, 4, 64, FS3D_PART_PF, 1>(c, p) : part_launch_xy<R, D0, 16, 8, 4, 32, FS3D_PART_PF, 1>(c, p);
+            if (n <= 256) return part_launch_xy<R, D0, 16, 16, 4, 64, FS3D_PART_PF, 1>(c, p);
             return false;
         }
         if (n <= 64) return part_launch_xy<R, DIR, 16, 4, 4, 32>(c, p);
@@ -1006,7 +1075,7 @@ template <typename R>
 bool launch_sweep_part(fs3d_ctx *c, int dir, const SweepParams<R> &p)
 {
     if ((unsigned long long)p.fstride * 4ull * sizeof(R) >= (1ull << 32)) return false;   // 32-bit buffer offsets span a layer
-    if (dir == 0 && (p.ghost_lo || p.ghost_hi) && !(p.carry_in && p.xcarry_in)) return false;   // X sweep of an x-slab: only with the values below / above the slab given
+    if (dir == 0 && (p.ghost_lo || p.ghost_hi) && !(p.carry_in && p.xcarry_in) && !p.xiface_pass) return false;   // X sweep of an x-slab: only with the values below / above the slab given
     if (dir == 0) return part_dispatch_xy<R, 0>(c, p);
     if (dir == 1) return part_dispatch_xy<R, 1>(c, p);
     return part_dispatch_z(c, p);

@@ -217,7 +217,8 @@ fs3d_status fs3d_profile_sweep(fs3d_ctx *ctx, int dir, double dt, int l_cur, int
 
 /* Which kernel the last sweep of direction dir (FS3D_DIR_*) really ran: FS3D_SWEEP_LINE / _PIPE / _PART, with
  * *segmented_out (optional): bit 0 = PIPE / LINE ran as halves through the HBM scratch (long lines, x-slabs); for dir X
- * of a multi-GPU group bits 1-2 = the cross-slab form that ran (1 pipelined, 2 reduced interface).  0 = no sweep yet.
+ * of a multi-GPU group bits 1-2 = the cross-slab form that ran (1 pipelined, 2 reduced interface, 3 reduced interface with
+ * the slab's interface words from a first pass of the partition kernel instead of the per-line walk).  0 = no sweep yet.
  * FS3D_SWEEP_AUTO never falls back silently: callers (bench.py, fs3d_run) print this. */
 fs3d_status fs3d_last_sweep_kernel(fs3d_ctx *ctx, int dir, int *kernel_out, int *segmented_out);
 

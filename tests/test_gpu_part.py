@@ -423,6 +423,50 @@ def test_slabs_reduced_interface_x_solve(built, nranks, dtype):
     grp.close()
 
 
+@pytest.mark.parametrize("dimx,nranks,onchip", [(64, 2, True), (64, 4, True), (96, 3, True), (128, 2, True), (64, 3, False), (70, 2, False)])
+def test_slab_interface_words_from_the_partition_kernel(built, dimx, nranks, onchip):
+    """Slabs of whole 16-plane chunks take their 18 interface words per line from a first pass of the X partition kernel
+    (rows and chunk elimination on chip) instead of the thread-per-line walk; other slab heights keep the walk.  One merged
+    X sweep on a seeded state and two steps, against ONE context on the same kernels: equal to rounding."""
+    from cmc_fluid_solver_amd.slab import slab_range
+    g = grids.box_with_obstacle(dimx, 24, 64, h=0.02)
+    params = capi.fluid_params(np.float32, *PARAMS)
+    base = [np.ascontiguousarray(a, np.float32) for a in (g.vx, g.vy, g.vz, g.T)]
+    cur, tmp = grids.perturb(base, seed=5), grids.perturb(base, seed=6)
+    s = capi.Solver(g, params, np.float32)
+    s.upload_layer(capi.LAYER_CUR, cur); s.upload_layer(capi.LAYER_TEMP, tmp)
+    s.sweep(0, DT, capi.LAYER_CUR, capi.LAYER_TEMP, capi.LAYER_NEXT, merge=True)
+    ref_next, ref_temp = s.download_layer(capi.LAYER_NEXT), s.download_layer(capi.LAYER_TEMP)
+    s.close()
+    s = capi.Solver(g, params, np.float32)
+    for i in range(2):
+        s.UpdateBoundaries(); s.TimeStep(DT, 4, 2, True)
+    ref_cur = s.download_layer(capi.LAYER_CUR); s.close()
+    grp = capi.LocalGroup(g, params, nranks, np.float32)
+
+    def work(r, sv):
+        x0, x1 = slab_range(g.dimx, r, nranks)
+        sv.upload_layer(capi.LAYER_CUR, [f[x0:x1] for f in cur]); sv.upload_layer(capi.LAYER_TEMP, [f[x0:x1] for f in tmp])
+        sv.sweep(0, DT, capi.LAYER_CUR, capi.LAYER_TEMP, capi.LAYER_NEXT, merge=True)
+        return sv.last_sweep_kernels()["X"], sv.download_layer(capi.LAYER_NEXT), sv.download_layer(capi.LAYER_TEMP)
+    res = grp.run(work)
+    grp.close()
+    assert all(("on-chip" in r[0]) == onchip and "reduced-interface" in r[0] for r in res), [r[0] for r in res]
+    for v in range(4):
+        nx = np.concatenate([r[1][v] for r in res], axis=0); tp = np.concatenate([r[2][v] for r in res], axis=0)
+        assert rel(nx, ref_next[v]) <= TOL_SWEEP and rel(tp, ref_temp[v]) <= TOL_SWEEP, "field %d: %.2e / %.2e" % (v, rel(nx, ref_next[v]), rel(tp, ref_temp[v]))
+    grp = capi.LocalGroup(g, params, nranks, np.float32)
+
+    def steps(r, sv):
+        for i in range(2):
+            sv.UpdateBoundaries(); sv.TimeStep(DT, 4, 2, True)
+        return sv.download_layer(capi.LAYER_CUR)
+    res = grp.run(steps)
+    grp.close()
+    full = [np.concatenate([r[v] for r in res], axis=0) for v in range(4)]
+    assert vec_rel(full, ref_cur) <= TOL_STEPS and rel(full[3], ref_cur[3]) <= TOL_STEPS
+
+
 def test_slabs_default_is_the_reduced_interface_solve(built):
     """FS3D_SWEEP_AUTO on slabs: partition kernels for Y and Z, the reduced-interface X solve; against one context (AUTO)."""
     g = grids.box(64, h=1.0 / 63)
