@@ -156,6 +156,8 @@ __global__ void __launch_bounds__(LT * NCH, WPS) k_sweep_part(SweepParams<R> p, 
         const int grp = (order & 0x20) ? (int)((blockIdx.x >> 3) % 3) : (int)((blockIdx.x >> 3) & 1);
         for (int w = grp * (order >> 8); w > 0; w--) __builtin_amdgcn_s_sleep(127);
     }
+    if ((order & 0x40) && blockIdx.x >= 256 && blockIdx.x < 512)      // two workgroups per CU: the second one of every CU starts late
+        for (int w = order >> 8; w > 0; w--) __builtin_amdgcn_s_sleep(127);
     PSTAMP(0);
 
     // XCD-aware block order (speed only): blocks b, b+8, .. share an XCD under round-robin dispatch; give each XCD a
