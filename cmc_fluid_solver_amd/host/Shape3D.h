@@ -1,0 +1,246 @@
+// Shape3D input surface in C++: the reference's `in_fmt Shape3D` triangle-mesh geometry rasterised into the Node array
+// the solver consumes.  Operation for operation (FTYPE = float, the reference's geometry type):
+//   Grid3D::Load3DShape                         (FluidSolver3D/Grid3D.cpp:373-431)
+//   BBox3D::Build, Grid3D::Init                 (Common/Geometry.h:510-529, Grid3D.cpp:351-371)
+//   Grid3D::Prepare3D_Shape / ComputeSubframeInfo / Build / RasterPolygon / ProjectPointOnPolygon / RasterLine / FloodFill
+//                                               (Grid3D.cpp:676-946)
+// File: frames; per frame: vertices, per vertex "x y z  vx vy vz", triangles, 3 indices each.  Frame duration 1/75 s; the
+// cycle length of a Shape3D run is Config::frame_time and GetFrame is always 0 (Grid3D.cpp:303-336).
+// Deviations, on purpose:
+//   * NODE_BOUND cells: the reference sets only their type; bc_vel / bc_temp keep whatever `new Node[]` left there
+//     (Grid3D.cpp:351-371, 818-838: SetData runs for NODE_IN / NODE_OUT only).  Here they read as zero-filled memory:
+//     BC_NOSLIP for both, v = 0, T = 0 (Init's values).
+//   * cells addressed outside the grid (the reference writes past its array) are ignored; a scan line that would never reach its
+//     end cell (the reference loops until the int wraps) throws.
+// Parity unpinned: the only shipped Shape3D case (large_tests/heart_us) carries a config the reference's parser rejects, and the
+// reference cannot be built here.  Python twin: cmc_fluid_solver_amd/shape3d.py (same operations; tests compare the two).
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <fstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "AdiSolver3D_hip.h"
+#include "Shape2D.h"
+
+namespace fs3d {
+
+struct Shape3DFrame {
+    std::vector<float> x, y, z, vx, vy, vz;   // vertices (physical, then grid coordinates) and their velocities (read, unused by the rasteriser)
+    std::vector<int> idx;                     // 3 per triangle
+    double duration = 1.0 / 75;               // Grid3D.cpp:413
+};
+
+struct Shape3D {
+    static constexpr float GRID_SCALE_FACTOR = 0.001f;       // Grid2D.h:31
+    static constexpr double COMP_EPS = 1e-8, BBOX_PADDING = 0.02, INF = 1e10;   // Geometry.h:22-24
+    std::vector<Shape3DFrame> frames;
+    float bbox[6] = {0, 0, 0, 0, 0, 0};       // pMin.xyz, pMax.xyz
+    int dimx = 0, dimy = 0, dimz = 0;
+    double dx = 0, dy = 0, dz = 0;
+    std::vector<uint8_t> type;
+
+    static float num(std::string tok) { std::replace(tok.begin(), tok.end(), ',', '.'); return (float)std::atof(tok.c_str()); }
+
+    void Load(const std::string &path, double dx_, double dy_, double dz_, bool align)
+    {
+        std::ifstream in(path.c_str());
+        if (!in) throw std::runtime_error("cannot open Shape3D file " + path);
+        std::vector<std::string> t;
+        for (std::string w; in >> w;) t.push_back(w);
+        size_t i = 0;
+        auto next = [&]() -> const std::string & { if (i >= t.size()) throw std::runtime_error("Shape3D file ends early"); return t[i++]; };
+        const int nf = std::atoi(next().c_str());
+        if (nf < 1) throw std::runtime_error("Shape3D file holds no frames");
+        frames.assign(nf, Shape3DFrame());
+        for (auto &fr : frames) {
+            const int nv = std::atoi(next().c_str());
+            for (int k = 0; k < nv; k++) {
+                const float px = num(next()), py = num(next()), pz = num(next());
+                fr.x.push_back(px * GRID_SCALE_FACTOR); fr.y.push_back(py * GRID_SCALE_FACTOR); fr.z.push_back(pz * GRID_SCALE_FACTOR);
+                fr.vx.push_back(num(next())); fr.vy.push_back(num(next())); fr.vz.push_back(num(next()));
+            }
+            const int nt = std::atoi(next().c_str());
+            for (int k = 0; k < 3 * nt; k++) {
+                const int v = std::atoi(next().c_str());
+                if (v < 0 || v >= nv) throw std::runtime_error("Shape3D: triangle index outside the vertex list");
+                fr.idx.push_back(v);
+            }
+        }
+        for (auto &fr : frames)
+            if (fr.x.size() != frames[0].x.size()) throw std::runtime_error("Shape3D: frames differ in their number of vertices");
+        dx = dx_; dy = dy_; dz = dz_;
+        // BBox3D::Build over all frames
+        float mn[3] = {(float)INF, (float)INF, (float)INF}, mx[3] = {(float)-INF, (float)-INF, (float)-INF};
+        for (auto &fr : frames)
+            for (size_t k = 0; k < fr.x.size(); k++) {
+                const float p[3] = {fr.x[k], fr.y[k], fr.z[k]};
+                for (int a = 0; a < 3; a++) { if (p[a] < mn[a]) mn[a] = p[a]; if (p[a] > mx[a]) mx[a] = p[a]; }
+            }
+        for (int a = 0; a < 3; a++) {
+            const float w = mx[a] - mn[a];
+            const float pad = w * (float)BBOX_PADDING;
+            mn[a] = mn[a] - pad; mx[a] = mx[a] + pad;
+            bbox[a] = mn[a]; bbox[3 + a] = mx[a];
+        }
+        // Grid3D::Init
+        dimx = (int)std::ceil((float)(mx[0] - mn[0]) / dx) + 1;
+        dimy = (int)std::ceil((float)(mx[1] - mn[1]) / dy) + 1;
+        dimz = (int)std::ceil((float)(mx[2] - mn[2]) / dz) + 1;
+        if (align) { dimx = AlignBy32(dimx); dimy = AlignBy32(dimy); dimz = AlignBy32(dimz); }
+        // physical -> grid coordinates (Grid3D.cpp:420-428)
+        for (auto &fr : frames)
+            for (size_t k = 0; k < fr.x.size(); k++) {
+                fr.x[k] = (float)(fr.x[k] - mn[0]) / (float)dx; fr.y[k] = (float)(fr.y[k] - mn[1]) / (float)dy; fr.z[k] = (float)(fr.z[k] - mn[2]) / (float)dz;
+            }
+        Prepare(0.0);
+    }
+
+    int GetFramesNum() const { return (int)frames.size(); }
+
+    // Grid3D::Prepare3D_Shape(time): ComputeSubframeInfo(frame, substep) + Build
+    void Prepare(double time)
+    {
+        const size_t nf = frames.size();
+        std::vector<double> a(nf + 1, 0.0);
+        for (size_t i = 1; i <= nf; i++) a[i] = a[i - 1] + frames[i - 1].duration;
+        const double r = std::fmod(time, a[nf]);
+        size_t frame = 0;
+        for (size_t i = 1; i < nf; i++) if (a[i] < r) frame = i;
+        const float s = (float)((r - a[frame]) / (a[frame + 1] - a[frame])), is = 1 - s;
+        const Shape3DFrame &f0 = frames[frame], &f1 = frames[(frame + 1) % nf];
+        Shape3DFrame sub;
+        sub.idx = f0.idx;
+        const size_t nv = f0.x.size();
+        sub.x.resize(nv); sub.y.resize(nv); sub.z.resize(nv);
+        for (size_t k = 0; k < nv; k++) {
+            sub.x[k] = mix(f0.x[k], is, f1.x[k], s); sub.y[k] = mix(f0.y[k], is, f1.y[k], s); sub.z[k] = mix(f0.z[k], is, f1.z[k], s);
+        }
+        Build(sub);
+    }
+
+private:
+    static float mix(float a, float wa, float b, float wb) { volatile float x = a * wa, y = b * wb; return x + y; }
+    static float fl(float v) { volatile float x = v; return x; }                    // one rounding to float, no contraction
+    size_t id(int i, int j, int k) const { return ((size_t)i * dimy + j) * dimz + k; }
+    void Set(int i, int j, int k, uint8_t c) { if (i >= 0 && j >= 0 && k >= 0 && i < dimx && j < dimy && k < dimz) type[id(i, j, k)] = c; }
+
+    struct V2 { float x, y; };
+    static V2 Horizon(V2 p1, V2 p2, V2 p)              // GetIntersectHorizon (Grid3D.cpp:676-685)
+    {
+        V2 r; r.y = p.y;
+        if (std::fabs(p1.y - p2.y) < COMP_EPS) r.x = p.x;
+        else r.x = fl(p1.x + fl(fl(fl(p2.x - p1.x) * fl(r.y - p1.y)) / fl(p2.y - p1.y)));
+        return r;
+    }
+    // ProjectPointOnPolygon (Grid3D.cpp:688-707): back onto the polygon's plane along its dominant axis
+    void Project(int dir, int i, int j, V2 tp, const float n[3], float d)
+    {
+        if (dir == 0) { const int k = (int)(fl(-d - fl(fl(tp.x * n[1]) + fl(tp.y * n[2]))) / n[0]); if (k >= 0 && k < dimx) Set(k, i, j, NODE_BOUND); }
+        else if (dir == 1) { const int k = (int)(fl(-d - fl(fl(tp.x * n[0]) + fl(tp.y * n[2]))) / n[1]); if (k >= 0 && k < dimy) Set(i, k, j, NODE_BOUND); }
+        else { const int k = (int)(fl(-d - fl(fl(tp.x * n[0]) + fl(tp.y * n[1]))) / n[2]); if (k >= 0 && k < dimz) Set(i, j, k, NODE_BOUND); }
+    }
+    void ScanHalf(V2 &p, float yend, V2 dp, V2 e1, V2 e2, int di, int dir, const float n[3], float d)
+    {
+        const long bound = 4l * (dimx + dimy + dimz) + 16;
+        for (; p.y < yend;) {
+            const int j = (int)p.y;
+            const int last_i = (int)Horizon(e1, e2, p).x;
+            long guard = 0;
+            for (int i = (int)p.x; i != last_i + di; i += di) {
+                if (++guard > bound) throw std::runtime_error("Shape3D: a scan line of a polygon never reaches its end cell (the reference loops there)");
+                Project(dir, i, j, V2{(float)i, p.y}, n, d);
+            }
+            p.x = fl(p.x + dp.x); p.y = fl(p.y + dp.y);
+        }
+    }
+    // RasterPolygon (Grid3D.cpp:709-789)
+    void RasterPolygon(const float p1[3], const float p2[3], const float p3[3])
+    {
+        auto eq = [](const float *a, const float *b) { return std::fabs(a[0] - b[0]) < COMP_EPS && std::fabs(a[1] - b[1]) < COMP_EPS && std::fabs(a[2] - b[2]) < COMP_EPS; };
+        if (eq(p1, p2) && eq(p1, p3)) return;
+        const float a[3] = {fl(p2[0] - p1[0]), fl(p2[1] - p1[1]), fl(p2[2] - p1[2])}, b[3] = {fl(p3[0] - p1[0]), fl(p3[1] - p1[1]), fl(p3[2] - p1[2])};
+        float n[3] = {fl(fl(a[1] * b[2]) - fl(a[2] * b[1])), fl(fl(a[2] * b[0]) - fl(a[0] * b[2])), fl(fl(a[0] * b[1]) - fl(a[1] * b[0]))};
+        const float len = (float)std::sqrt(fl(fl(fl(n[0] * n[0]) + fl(n[1] * n[1])) + fl(n[2] * n[2])));
+        const float t = 1 / len;
+        n[0] = fl(n[0] * t); n[1] = fl(n[1] * t); n[2] = fl(n[2] * t);
+        const float d = -fl(fl(fl(p1[0] * n[0]) + fl(p1[1] * n[1])) + fl(p1[2] * n[2]));
+        const float maxv = std::max(std::fabs(n[0]), std::max(std::fabs(n[1]), std::fabs(n[2])));
+        int dir = 0;                                                          // the reference leaves it unset when no test passes (NaN normal)
+        if (std::fabs(maxv - std::fabs(n[0])) < COMP_EPS) dir = 0;
+        if (std::fabs(maxv - std::fabs(n[1])) < COMP_EPS) dir = 1;
+        if (std::fabs(maxv - std::fabs(n[2])) < COMP_EPS) dir = 2;
+        if (!(len > 0)) return;                                               // degenerate triangle (collinear vertices): no plane
+        V2 pp1, pp2, pp3;
+        if (dir == 0) { pp1 = {p1[1], p1[2]}; pp2 = {p2[1], p2[2]}; pp3 = {p3[1], p3[2]}; }
+        else if (dir == 1) { pp1 = {p1[0], p1[2]}; pp2 = {p2[0], p2[2]}; pp3 = {p3[0], p3[2]}; }
+        else { pp1 = {p1[0], p1[1]}; pp2 = {p2[0], p2[1]}; pp3 = {p3[0], p3[1]}; }
+        V2 mid;
+        if (pp3.y < pp2.y) { mid = pp3; pp3 = pp2; pp2 = mid; }
+        if (pp1.y > pp2.y) { mid = pp1; pp1 = pp2; pp2 = mid; }
+        if (pp3.y < pp2.y) { mid = pp3; pp3 = pp2; pp2 = mid; }
+        mid = Horizon(pp1, pp3, pp2);
+        const V2 dir1{fl(mid.x - pp1.x), fl(mid.y - pp1.y)}, dir2{fl(pp3.x - mid.x), fl(pp3.y - mid.y)};
+        const int steps1 = (int)std::max(std::fabs(dir1.x), std::fabs(dir1.y)) + 1, steps2 = (int)std::max(std::fabs(dir2.x), std::fabs(dir2.y)) + 1;
+        const V2 dp1{dir1.x / steps1, dir1.y / steps1}, dp2{dir2.x / steps2, dir2.y / steps2};
+        V2 p = pp1;
+        const int di = (mid.x < pp2.x) ? 1 : -1;
+        ScanHalf(p, mid.y, dp1, pp1, pp2, di, dir, n, d);
+        ScanHalf(p, pp3.y, dp2, pp2, pp3, di, dir, n, d);
+    }
+    // RasterLine (Grid3D.cpp:791-811)
+    void RasterLine(const float p1[3], const float p2[3])
+    {
+        const float dir[3] = {fl(p2[0] - p1[0]), fl(p2[1] - p1[1]), fl(p2[2] - p1[2])};
+        const int steps = (int)std::max(std::fabs(dir[0]), std::max(std::fabs(dir[1]), std::fabs(dir[2]))) + 1;
+        const float dp[3] = {dir[0] / (float)steps, dir[1] / (float)steps, dir[2] / (float)steps};
+        float p[3] = {p1[0], p1[1], p1[2]};
+        for (int i = 0; i <= steps; i++) {
+            Set((int)p[0], (int)p[1], (int)p[2], NODE_BOUND);
+            p[0] = fl(p[0] + dp[0]); p[1] = fl(p[1] + dp[1]); p[2] = fl(p[2] + dp[2]);
+        }
+    }
+    // Grid3D::Build (Grid3D.cpp:859-903) + FloodFill (:813-857)
+    void Build(const Shape3DFrame &fr)
+    {
+        type.assign((size_t)dimx * dimy * dimz, NODE_IN);
+        for (size_t q = 0; q + 2 < fr.idx.size(); q += 3) {
+            const int i1 = fr.idx[q], i2 = fr.idx[q + 1], i3 = fr.idx[q + 2];
+            const float p1[3] = {fr.x[i1], fr.y[i1], fr.z[i1]}, p2[3] = {fr.x[i2], fr.y[i2], fr.z[i2]}, p3[3] = {fr.x[i3], fr.y[i3], fr.z[i3]};
+            RasterPolygon(p1, p2, p3);
+            RasterLine(p1, p2); RasterLine(p1, p3); RasterLine(p3, p2);       // the edges as well, to cover holes
+        }
+        std::vector<int> queue;
+        queue.reserve(3 * 4096);
+        auto push = [&](int i, int j, int k) { queue.push_back(i); queue.push_back(j); queue.push_back(k); type[id(i, j, k)] = NODE_OUT; };
+        push(0, 0, 0);                                                        // (the reference marks (0,0,0) whatever it was)
+        const int nb[18] = {-1, 0, 0, 1, 0, 0, 0, -1, 0, 0, 1, 0, 0, 0, -1, 0, 0, 1};
+        for (size_t cur = 0; cur * 3 < queue.size(); cur++) {
+            const int i = queue[cur * 3], j = queue[cur * 3 + 1], k = queue[cur * 3 + 2];
+            for (int q = 0; q < 6; q++) {
+                const int a = i + nb[3 * q], b = j + nb[3 * q + 1], c = k + nb[3 * q + 2];
+                if (a >= 0 && a < dimx && b >= 0 && b < dimy && c >= 0 && c < dimz && type[id(a, b, c)] == NODE_IN) push(a, b, c);
+            }
+        }
+    }
+};
+
+// Grid3D(dx,dy,dz,baseT) + LoadFromFile + Prepare_CPU(0) for a Shape3D input (FluidSolver3D.cpp:121-145)
+template <typename FTYPE>
+void LoadShape3D(Grid3D<FTYPE> &g, Shape3D &sh, const std::string &path, double dx, double dy, double dz, double baseT, bool align)
+{
+    sh.Load(path, dx, dy, dz, align);
+    g.Resize(sh.dimx, sh.dimy, sh.dimz);
+    g.dx = dx; g.dy = dy; g.dz = dz; g.baseT = baseT;
+    for (size_t c = 0; c < sh.type.size(); c++) {
+        g.type[c] = sh.type[c];
+        g.bc_vel[c] = BC_NOSLIP; g.bc_temp[c] = BC_NOSLIP;
+        g.vx[c] = 0; g.vy[c] = 0; g.vz[c] = 0;
+        g.T[c] = sh.type[c] == NODE_BOUND ? (FTYPE)0 : (FTYPE)(float)baseT;     // Init: T = 0; Build: SetData(.., baseT) on NODE_IN / NODE_OUT only
+    }
+}
+
+}  // namespace fs3d

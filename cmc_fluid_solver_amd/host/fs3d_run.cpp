@@ -1,6 +1,6 @@
 // Command-line driver: the reference's FluidSolver3D main (FluidSolver3D/FluidSolver3D.cpp:60-330) on top of
 // libfs3d_hip.so.   fs3d_run <input data> <output prefix> <config> [align] [GPU [n]] [double] [--steps N] [--same-device] [--grid-only FILE]
-//   * reads the config (host/Config.h) and a Shape2D geometry (host/Shape2D.h), prints the grid summary lines
+//   * reads the config (host/Config.h) and a Shape2D or Shape3D geometry (host/Shape2D.h, host/Shape3D.h), prints the grid summary lines
 //     the reference prints ("Grid = X x Y x Z", "NODE_IN points = ..."),
 //   * runs the same loop: dt = cycle length / (frames * time_steps), UpdateBoundaries + TimeStep per step with the
 //     divergence error every 10th step and on the last one, "err = ..." and the progress line per step,
@@ -26,9 +26,19 @@
 #include "Config.h"
 #include "NetCDF3.h"
 #include "Shape2D.h"
+#include "Shape3D.h"
+
+// what the time loop and the result header need from the geometry (Grid3D::GetFramesNum / GetCycleLength / GetFrame / GetBBox)
+struct RunGeom {
+    int frames = 1;
+    double length = 0;
+    float bbox[6] = {0, 0, 0, 0, 0, 0};
+    const fs3d::Grid2D *g2 = nullptr;                 // Shape2D: frames in time; Shape3D: frame 0 throughout (Grid3D.cpp:322-328)
+    int GetFrame(double t) const { return g2 ? g2->GetFrame(t) : 0; }
+};
 
 template <typename FTYPE>
-static int run_slabs(const fs3d::Grid3D<FTYPE> &grid, const fs3d::Grid2D &g2, const std::string &prefix, const fs3d::Config &cfg, int nslabs,
+static int run_slabs(const fs3d::Grid3D<FTYPE> &grid, const RunGeom &geo, const std::string &prefix, const fs3d::Config &cfg, int nslabs,
                      bool same_device, long max_steps, bool csv);
 
 template <typename FTYPE>
@@ -38,7 +48,20 @@ static int run(const std::string &data, const std::string &prefix, const fs3d::C
     using namespace fs3d;
     Grid3D<FTYPE> grid;
     Grid2D g2;
-    LoadShape2D(grid, g2, data, cfg.dx, cfg.dy, cfg.dz, cfg.depth, cfg.depth_var, cfg.baseT, align);
+    Shape3D sh3;
+    RunGeom geo;
+    if (cfg.in_fmt == "Shape3D") {
+        std::printf("Geometry: 3D polygons\n");                                                  // FluidSolver3D.cpp:121-126
+        LoadShape3D(grid, sh3, data, cfg.dx, cfg.dy, cfg.dz, cfg.baseT, align);
+        geo.frames = sh3.GetFramesNum(); geo.length = cfg.frame_time;                            // Grid3D.cpp:298-309
+        for (int a = 0; a < 6; a++) geo.bbox[a] = sh3.bbox[a];
+    } else {
+        std::printf("Geometry: extruded 2D shape\n");                                            // :127-132
+        LoadShape2D(grid, g2, data, cfg.dx, cfg.dy, cfg.dz, cfg.depth, cfg.depth_var, cfg.baseT, align);
+        geo.frames = g2.GetFramesNum(); geo.length = g2.GetCycleLenght(); geo.g2 = &g2;
+        const float bb[6] = {g2.bbox[0], g2.bbox[1], 0.0f, g2.bbox[2], g2.bbox[3], (float)cfg.depth};   // BBox3D(bbox2D, depth), :203
+        for (int a = 0; a < 6; a++) geo.bbox[a] = bb[a];
+    }
     std::printf("Grid = %i x %i x %i\n", grid.dimx, grid.dimy, grid.dimz);                      // FluidSolver3D.cpp:146
     double inside = 0;
     for (uint8_t t : grid.type) inside += t == NODE_IN;
@@ -55,20 +78,20 @@ static int run(const std::string &data, const std::string &prefix, const fs3d::C
         std::fclose(f);
         return 0;
     }
-    if (nslabs > 1) return run_slabs<FTYPE>(grid, g2, prefix, cfg, nslabs, same_device, max_steps, csv);
+    if (nslabs > 1) return run_slabs<FTYPE>(grid, geo, prefix, cfg, nslabs, same_device, max_steps, csv);
     FluidParams<FTYPE> params = cfg.useNormalizedParams ? FluidParams<FTYPE>(cfg.Re, cfg.Pr, cfg.lambda)
                                                         : FluidParams<FTYPE>(cfg.viscosity, cfg.density, cfg.R_specific, cfg.k, cfg.cv);
     AdiSolver3D<FTYPE> solver;
     solver.Init(device, grid, params);
     std::printf("Segments: %i %i %i (x, y, z)\n", solver.numSegs[0], solver.numSegs[1], solver.numSegs[2]);
 
-    const int frames = g2.GetFramesNum();                              // FluidSolver3D.cpp:194-195
-    const double length = g2.GetCycleLenght();
+    const int frames = geo.frames;                                     // FluidSolver3D.cpp:194-195
+    const double length = geo.length;
     const double dt = length / (frames * cfg.time_steps);              // :196
     const double finaltime = length * cfg.cycles;
     const std::string out = prefix + "_res.nc";
     NetCDF3Writer nc;
-    const float bbox[6] = {g2.bbox[0], g2.bbox[1], 0.0f, g2.bbox[2], g2.bbox[3], (float)cfg.depth};   // BBox3D(bbox2D, depth), :203
+    const float *bbox = geo.bbox;
     nc.Create(out, bbox, dt * cfg.out_time_steps, finaltime, cfg.outdimx, cfg.outdimy, cfg.outdimz, cfg.out_vars);
     std::vector<FTYPE> resVel((size_t)cfg.outdimx * cfg.outdimy * cfg.outdimz * 3);
     std::vector<double> resT((size_t)cfg.outdimx * cfg.outdimy * cfg.outdimz);
@@ -81,7 +104,7 @@ static int run(const std::string &data, const std::string &prefix, const fs3d::C
     // the geometry is frame 0's for the whole run: the reference prepares the grid once, before the loop (grid->Prepare(0), :226;
     // the per-step grid->Prepare(t) is commented out, :237) -- the frame only restarts the substep counter
     for (int i = 0; t < finaltime && (max_steps < 0 || steps < max_steps); t += dt, i++, steps++) {
-        const int currentframe = g2.GetFrame(t);                                                         // :229-236
+        const int currentframe = geo.GetFrame(t);                                                        // :229-236
         if (currentframe != lastframe) { lastframe = currentframe; i = 0; }
         solver.UpdateBoundaries();                                                                       // :244
         solver.TimeStep((FTYPE)dt, cfg.num_global, cfg.num_local, (i % 10 == 0) || (t + dt >= finaltime)); // :245
@@ -148,16 +171,16 @@ struct Barrier {
 }
 
 template <typename FTYPE>
-static int run_slabs(const fs3d::Grid3D<FTYPE> &grid, const fs3d::Grid2D &g2, const std::string &prefix, const fs3d::Config &cfg, int nslabs,
+static int run_slabs(const fs3d::Grid3D<FTYPE> &grid, const RunGeom &geo, const std::string &prefix, const fs3d::Config &cfg, int nslabs,
                      bool same_device, long max_steps, bool csv)
 {
     using namespace fs3d;
     FluidParams<FTYPE> params = cfg.useNormalizedParams ? FluidParams<FTYPE>(cfg.Re, cfg.Pr, cfg.lambda)
                                                         : FluidParams<FTYPE>(cfg.viscosity, cfg.density, cfg.R_specific, cfg.k, cfg.cv);
-    const double length = g2.GetCycleLenght(), dt = length / (g2.GetFramesNum() * cfg.time_steps), finaltime = length * cfg.cycles;
+    const double length = geo.length, dt = length / (geo.frames * cfg.time_steps), finaltime = length * cfg.cycles;
     const std::string out = prefix + "_res.nc";
     NetCDF3Writer nc;
-    const float bbox[6] = {g2.bbox[0], g2.bbox[1], 0.0f, g2.bbox[2], g2.bbox[3], (float)cfg.depth};
+    const float *bbox = geo.bbox;
     nc.Create(out, bbox, dt * cfg.out_time_steps, finaltime, cfg.outdimx, cfg.outdimy, cfg.outdimz, cfg.out_vars);
     const size_t ncell = (size_t)grid.dimx * grid.dimy * grid.dimz, plane = (size_t)grid.dimy * grid.dimz;
     std::vector<FTYPE> fullV(ncell * 3), resVel((size_t)cfg.outdimx * cfg.outdimy * cfg.outdimz * 3);
@@ -181,7 +204,7 @@ static int run_slabs(const fs3d::Grid3D<FTYPE> &grid, const fs3d::Grid2D &g2, co
                 long steps = 0;
                 int lastframe = -1;
                 for (int i = 0; t < finaltime && (max_steps < 0 || steps < max_steps); t += dt, i++, steps++) {
-                    const int currentframe = g2.GetFrame(t);
+                    const int currentframe = geo.GetFrame(t);
                     if (currentframe != lastframe) { lastframe = currentframe; i = 0; }
                     solver.UpdateBoundaries();
                     solver.TimeStep((FTYPE)dt, cfg.num_global, cfg.num_local, (i % 10 == 0) || (t + dt >= finaltime));
@@ -237,7 +260,8 @@ int main(int argc, char **argv)
         fs3d::Config cfg;
         cfg.Load(argv[3]);
         if (cfg.problem_dim != "3D") throw std::runtime_error("only `dimension 3D` runs are supported");
-        if (cfg.in_fmt != "Shape2D") throw std::runtime_error("in_fmt " + cfg.in_fmt + ": only Shape2D inputs are supported");
+        if (cfg.in_fmt != "Shape2D" && cfg.in_fmt != "Shape3D") throw std::runtime_error("in_fmt " + cfg.in_fmt + ": only Shape2D and Shape3D inputs are supported");
+        if (cfg.in_fmt == "Shape3D" && !(cfg.frame_time > 0)) throw std::runtime_error("must specify frame time!");   // the cycle length of a Shape3D run (Grid3D.cpp:303-309)
         if (cfg.solver != "ADI") throw std::runtime_error("solver " + cfg.solver + " is not implemented (the reference implements ADI only)");
         bool align = false, dbl = false, csv = false, same_device = false;
         int nslabs = 1;
