@@ -6,7 +6,8 @@
 // the netCDF *classic* format, 64-bit-offset variant (CDF-2), by hand -- the same data model, read by ncdump,
 // ncview, netCDF4-python and scipy.io.netcdf_file alike.  Difference kept on purpose: `time` is a record variable
 // here and receives its value when a layer is appended (the reference pre-fills all time values in the header call).
-// The optional depth variable `d` (SeaNetCDF inputs) is not supported.
+// The optional depth variable `d` (SeaNetCDF inputs: float (x, y), the depth map resampled to the output grid) is a fixed-size
+// variable written with the header, as in the reference.
 #pragma once
 #include <cstdint>
 #include <cstdio>
@@ -62,7 +63,7 @@ class NetCDF3Writer {
 public:
     // OutputNetCDF3D_header: bbox = {xmin, ymin, zmin, xmax, ymax, zmax}; timestep = dt * out_time_steps; time = final time
     void Create(const std::string &path, const float bbox[6], double timestep, double time, int outdimx, int outdimy, int outdimz,
-                const std::vector<std::string> &vars, bool xy_degree_units = false)
+                const std::vector<std::string> &vars, bool xy_degree_units = false, const float *depth_xy = nullptr)
     {
         path_ = path; outx_ = outdimx; outy_ = outdimy; outz_ = outdimz; timestep_ = timestep; numrecs_ = 0;
         const std::vector<std::string> dimname{"x", "y", "z", "t"};
@@ -97,13 +98,26 @@ public:
             v.atts.push_back(text("long_name", vlong[i])); v.atts.push_back(text("var_desc", vshort[i]));
             vars_.push_back(v);
         }
-        for (const auto &s : vars) if (s == "d") throw std::runtime_error("out_vars: the depth variable `d` is not supported");
+        bool use_d = false;
+        for (const auto &s : vars) use_d = use_d || s == "d";
+        if (use_d) {
+            // the reference dereferences a null DepthInfo3D for inputs that carry no depth map (IO.h:270-273); here it is an error
+            if (!depth_xy) throw std::runtime_error("out_vars: the depth variable `d` needs a SeaNetCDF input");
+            Var v{"d", NC_FLOAT, {0, 1}, {}, false};
+            const double rng[2] = {-1.0, 1.0};
+            const float miss = 99999.0f;
+            v.atts.push_back(text("units", "m"));
+            v.atts.push_back(doubles("actual_range", rng, 2)); v.atts.push_back(doubles("valid_range", rng, 2));
+            v.atts.push_back(floats("missing_value", &miss, 1));
+            v.atts.push_back(text("long_name", "depth")); v.atts.push_back(text("var_desc", "d"));
+            vars_.push_back(v);
+        }
         const std::vector<Att> gatts{text("Conventions", "COARDS"), text("title", "cmc-fluid-solver results"),
                                      text("history", "created by using cmc-fluid-solver"), text("description", "Test data"), text("platform", "Model")};
         // sizes and offsets: fixed variables first, then the records
         const uint64_t cells = (uint64_t)outdimx * outdimy * outdimz;
         if (cells * 8 >= 0xFFFFFFFCull) throw std::runtime_error("output grid too large for one netCDF classic record variable (>= 4 GiB per layer)");
-        for (Var &v : vars_) v.vsize = v.record ? (v.dims.size() == 1 ? 8 : cells * 8) : (uint64_t)dimlen[v.dims[0]] * 4;
+        for (Var &v : vars_) v.vsize = v.record ? (v.dims.size() == 1 ? 8 : cells * 8) : (v.dims.size() == 2 ? (uint64_t)outdimx * outdimy * 4 : (uint64_t)dimlen[v.dims[0]] * 4);
         for (Var &v : vars_) v.vsize = (v.vsize + 3) / 4 * 4;
         uint64_t off = header(dimlen, dimname, gatts).size();
         for (Var &v : vars_) if (!v.record) { v.begin = off; off += v.vsize; }
@@ -119,6 +133,11 @@ public:
             const float dd = (float)(bbox[3 + a] - bbox[a]) / (od[a]);
             std::vector<unsigned char> b;
             for (int i = 0; i < od[a]; i++) { const float x = bbox[a] + dd * i; be(b, &x, 4); }
+            std::fwrite(b.data(), 1, b.size(), f);
+        }
+        if (use_d) {                                           // after x, y, z: the order of vars_ (fixed-size variables in definition order)
+            std::vector<unsigned char> b;
+            for (size_t c = 0; c < (size_t)outdimx * outdimy; c++) be(b, &depth_xy[c], 4);
             std::fwrite(b.data(), 1, b.size(), f);
         }
         std::fclose(f);

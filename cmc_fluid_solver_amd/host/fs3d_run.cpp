@@ -1,6 +1,6 @@
 // Command-line driver: the reference's FluidSolver3D main (FluidSolver3D/FluidSolver3D.cpp:60-330) on top of
 // libfs3d_hip.so.   fs3d_run <input data> <output prefix> <config> [align] [GPU [n]] [double] [--steps N] [--same-device] [--grid-only FILE]
-//   * reads the config (host/Config.h) and a Shape2D or Shape3D geometry (host/Shape2D.h, host/Shape3D.h), prints the grid summary lines
+//   * reads the config (host/Config.h) and a Shape2D, Shape3D or SeaNetCDF geometry (host/Shape2D.h, Shape3D.h, SeaNetCDF.h), prints the grid summary lines
 //     the reference prints ("Grid = X x Y x Z", "NODE_IN points = ..."),
 //   * runs the same loop: dt = cycle length / (frames * time_steps), UpdateBoundaries + TimeStep per step with the
 //     divergence error every 10th step and on the last one, "err = ..." and the progress line per step,
@@ -27,13 +27,15 @@
 #include "NetCDF3.h"
 #include "Shape2D.h"
 #include "Shape3D.h"
+#include "SeaNetCDF.h"
 
 // what the time loop and the result header need from the geometry (Grid3D::GetFramesNum / GetCycleLength / GetFrame / GetBBox)
 struct RunGeom {
     int frames = 1;
     double length = 0;
     float bbox[6] = {0, 0, 0, 0, 0, 0};
-    const fs3d::Grid2D *g2 = nullptr;                 // Shape2D: frames in time; Shape3D: frame 0 throughout (Grid3D.cpp:322-328)
+    const fs3d::Grid2D *g2 = nullptr;                 // Shape2D: frames in time; Shape3D / SeaNetCDF: frame 0 throughout (Grid3D.cpp:322-328)
+    const fs3d::DepthInfo3D *depths = nullptr;        // SeaNetCDF: the depth map (`d` output variable), x / y in degrees
     int GetFrame(double t) const { return g2 ? g2->GetFrame(t) : 0; }
 };
 
@@ -50,7 +52,13 @@ static int run(const std::string &data, const std::string &prefix, const fs3d::C
     Grid2D g2;
     Shape3D sh3;
     RunGeom geo;
-    if (cfg.in_fmt == "Shape3D") {
+    SeaNetCDF sea;
+    if (cfg.in_fmt == "SeaNetCDF") {
+        std::printf("Geometry: depths from NetCDF\n");                                           // FluidSolver3D.cpp:133-138
+        sea.Load(grid, data, cfg.dx, cfg.dy, cfg.dz, cfg.baseT, cfg.bc_inV, cfg.bc_inT, align);
+        geo.frames = 1; geo.length = cfg.frame_time; geo.depths = &sea.depths;                   // num_frames = 1, Grid3D.cpp:483
+        for (int a = 0; a < 6; a++) geo.bbox[a] = sea.bbox[a];
+    } else if (cfg.in_fmt == "Shape3D") {
         std::printf("Geometry: 3D polygons\n");                                                  // FluidSolver3D.cpp:121-126
         LoadShape3D(grid, sh3, data, cfg.dx, cfg.dy, cfg.dz, cfg.baseT, align);
         geo.frames = sh3.GetFramesNum(); geo.length = cfg.frame_time;                            // Grid3D.cpp:298-309
@@ -92,7 +100,10 @@ static int run(const std::string &data, const std::string &prefix, const fs3d::C
     const std::string out = prefix + "_res.nc";
     NetCDF3Writer nc;
     const float *bbox = geo.bbox;
-    nc.Create(out, bbox, dt * cfg.out_time_steps, finaltime, cfg.outdimx, cfg.outdimy, cfg.outdimz, cfg.out_vars);
+    DepthInfo3D out_depths;                                                                  // IO.h:270-273
+    if (geo.depths) out_depths = DepthInfo3D(cfg.outdimx, cfg.outdimy, *geo.depths);
+    nc.Create(out, bbox, dt * cfg.out_time_steps, finaltime, cfg.outdimx, cfg.outdimy, cfg.outdimz, cfg.out_vars, geo.depths != nullptr,
+              geo.depths ? out_depths.depth.data() : nullptr);
     std::vector<FTYPE> resVel((size_t)cfg.outdimx * cfg.outdimy * cfg.outdimz * 3);
     std::vector<double> resT((size_t)cfg.outdimx * cfg.outdimy * cfg.outdimz);
 
@@ -181,7 +192,10 @@ static int run_slabs(const fs3d::Grid3D<FTYPE> &grid, const RunGeom &geo, const 
     const std::string out = prefix + "_res.nc";
     NetCDF3Writer nc;
     const float *bbox = geo.bbox;
-    nc.Create(out, bbox, dt * cfg.out_time_steps, finaltime, cfg.outdimx, cfg.outdimy, cfg.outdimz, cfg.out_vars);
+    DepthInfo3D out_depths;                                                                  // IO.h:270-273
+    if (geo.depths) out_depths = DepthInfo3D(cfg.outdimx, cfg.outdimy, *geo.depths);
+    nc.Create(out, bbox, dt * cfg.out_time_steps, finaltime, cfg.outdimx, cfg.outdimy, cfg.outdimz, cfg.out_vars, geo.depths != nullptr,
+              geo.depths ? out_depths.depth.data() : nullptr);
     const size_t ncell = (size_t)grid.dimx * grid.dimy * grid.dimz, plane = (size_t)grid.dimy * grid.dimz;
     std::vector<FTYPE> fullV(ncell * 3), resVel((size_t)cfg.outdimx * cfg.outdimy * cfg.outdimz * 3);
     std::vector<double> fullT(ncell), resT((size_t)cfg.outdimx * cfg.outdimy * cfg.outdimz);
@@ -260,8 +274,8 @@ int main(int argc, char **argv)
         fs3d::Config cfg;
         cfg.Load(argv[3]);
         if (cfg.problem_dim != "3D") throw std::runtime_error("only `dimension 3D` runs are supported");
-        if (cfg.in_fmt != "Shape2D" && cfg.in_fmt != "Shape3D") throw std::runtime_error("in_fmt " + cfg.in_fmt + ": only Shape2D and Shape3D inputs are supported");
-        if (cfg.in_fmt == "Shape3D" && !(cfg.frame_time > 0)) throw std::runtime_error("must specify frame time!");   // the cycle length of a Shape3D run (Grid3D.cpp:303-309)
+        if (cfg.in_fmt != "Shape2D" && cfg.in_fmt != "Shape3D" && cfg.in_fmt != "SeaNetCDF") throw std::runtime_error("in_fmt " + cfg.in_fmt + ": unknown input format");
+        if (cfg.in_fmt != "Shape2D" && !(cfg.frame_time > 0)) throw std::runtime_error("must specify frame time!");   // the cycle length of a Shape3D run (Grid3D.cpp:303-309)
         if (cfg.solver != "ADI") throw std::runtime_error("solver " + cfg.solver + " is not implemented (the reference implements ADI only)");
         bool align = false, dbl = false, csv = false, same_device = false;
         int nslabs = 1;

@@ -8,6 +8,11 @@ int main(int argc, char **argv)
     const int nx = 3, ny = 4, nz = 5;
     const float bbox[6] = {-0.5f, 0.25f, 0.0f, 1.5f, 2.25f, 1.0f};
     fs3d::NetCDF3Writer nc;
+    if (argc > 2) {                                        // sea mode: degree units and the depth variable `d` (x, y)
+        std::vector<float> d(nx * ny);
+        for (int c = 0; c < nx * ny; c++) d[c] = -10.0f * c + 0.5f;
+        nc.Create(argv[1], bbox, 0.5, 10.0, nx, ny, nz, {"u", "d"}, true, d.data());
+    } else
     nc.Create(argv[1], bbox, 0.5, 10.0, nx, ny, nz, {"u", "w", "T"});
     std::vector<float> vel(nx * ny * nz * 3);
     std::vector<double> T(nx * ny * nz);

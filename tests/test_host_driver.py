@@ -106,6 +106,25 @@ def test_netcdf_writer_roundtrip(tmp_path):
     f.close()
 
 
+def test_netcdf_writer_depth_variable_and_degree_units(tmp_path):
+    """SeaNetCDF runs: x / y in degrees and the fixed-size variable `d` (x, y) beside the records (IO.h:168-171, 188-196, 270-273)."""
+    from scipy.io import netcdf_file
+    exe = os.path.join(HERE, "netcdf_writer_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(HERE, "netcdf_writer_test.cpp"), "-o", exe])
+    path = str(tmp_path / "sea_res.nc")
+    assert subprocess.run([exe, path, "sea"], check=True, capture_output=True, text=True).stdout.strip() == "3"
+    f = netcdf_file(path, "r", mmap=False)
+    assert set(f.variables) == {"x", "y", "z", "time", "u", "d"}
+    assert f.variables["x"].units == b"degree_north" and f.variables["y"].units == b"degree_east" and f.variables["z"].units == b"metres"
+    d = f.variables["d"]
+    assert d.dimensions == ("x", "y") and d.units == b"m" and d.long_name == b"depth" and float(d.missing_value) == 99999.0
+    np.testing.assert_array_equal(d[:], (-10.0 * np.arange(12) + 0.5).reshape(3, 4).astype(np.float32))
+    assert f.variables["u"].shape == (3, 3, 4, 5)
+    np.testing.assert_array_equal(f.variables["u"][1], 100.0 + np.arange(60).reshape(3, 4, 5))
+    np.testing.assert_array_equal(f.variables["time"][:], [0.0, 0.5, 1.0])
+    f.close()
+
+
 @pytest.mark.gpu
 def test_driver_runs_the_shipped_example(driver, tmp_path):
     """fs3d_run on data/3D box_pipe (the fixture copy): err values and the result layers equal the Python path's."""

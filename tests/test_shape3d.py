@@ -151,15 +151,18 @@ def test_driver_runs_a_shape3d_input(driver, sphere_case, monkeypatch):
     prefix = str(d / "run")
     out = subprocess.run([driver, data, prefix, cfg, "align", "GPU"], check=True, capture_output=True, text=True).stdout
     nodes, sh = shape3d.load_shape3d(data, float(np.float32(0.001)), float(np.float32(0.001)), float(np.float32(0.001)), align=True)
-    dt = 0.4 / (2 * 4)
+    from cmc_fluid_solver_amd import shape2d
+    c = shape2d.Config(cfg)                                      # frame_time goes through a float, like every real number of a config
+    dt = c.frame_time / (2 * c.time_steps)
+    final = c.frame_time * c.cycles
     nsteps = len(re.findall(r"substep (\d+)", out))
     assert nsteps in (7, 8) and set(re.findall(r"frame (\d+)\tsubstep", out)) == {"0"}
-    s = capi.Solver(nodes, capi.fluid_params(np.float32, 200.0, 0.72, 1.4), np.float32)
+    s = capi.Solver(nodes, capi.fluid_params(np.float32, c.Re, c.Pr, c.lam), np.float32)
     layers, errs = [], []
     t = dt
     for i in range(nsteps):
         s.UpdateBoundaries()
-        errs.append(s.TimeStep(np.float32(dt), 2, 1, i % 10 == 0 or t + dt >= 0.4))
+        errs.append(s.TimeStep(np.float32(dt), 2, 1, i % 10 == 0 or t + dt >= final))
         if i % 2 == 0:
             layers.append(s.GetLayer((16, 16, 16)))
         t += dt
