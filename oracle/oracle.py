@@ -28,8 +28,10 @@ def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
     srcs = [os.path.join(_HERE, f) for f in ("fs3d_oracle.c", "fs3d_oracle_body.inc")]
     stale = (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
-    ref_missing = os.path.isdir("/root/reference/src/Common") and not os.path.exists(
-        os.path.join(_HERE, "_ref", "libref_pieces.so"))
+    ref_srcs = [os.path.join(_HERE, f) for f in ("ref_harness_f32.cpp", "ref_harness_f64.cpp", "ref_harness_cfg.cpp")]
+    ref_sos = [os.path.join(_HERE, "_ref", f) for f in ("libref_pieces.so", "libref_config.so")]
+    ref_missing = os.path.isdir("/root/reference/src/Common") and (
+        not all(os.path.exists(p) for p in ref_sos) or any(os.path.getmtime(s) > min(os.path.getmtime(p) for p in ref_sos) for s in ref_srcs))
     if force or stale or ref_missing:
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return so
@@ -108,7 +110,39 @@ def ref_lib():
         _REF.ref_fluid_params_physical_f32.argtypes = [C.c_double] * 5 + [pf]
         _REF.ref_align_by_32.argtypes = [C.c_int]
         _REF.ref_align_by_32.restype = C.c_int
+        pi = C.POINTER(C.c_int)
+        if hasattr(_REF, "ref_bbox2d_build"):
+            _REF.ref_bbox2d_build.argtypes = [C.c_int, pi, pf, pf]
+            _REF.ref_bbox3d_build.argtypes = [C.c_int, pi, pf, pf]
+            _REF.ref_depth_resample.argtypes = [C.c_int] * 4 + [pf, pf]
     return _REF
+
+
+def ref_config(path):
+    """The reference's own Config::LoadFromFile (oracle/_ref/libref_config.so: Common/Config.h + LinuxIO.cpp compiled as they lie)
+    on `path`, in a child process (the reference calls exit(0) on a config it rejects) -> dict, or None when it rejected the file /
+    the library is not there."""
+    build()
+    so = os.path.join(_HERE, "_ref", "libref_config.so")
+    if not os.path.exists(so):
+        return None
+    code = ("import ctypes as C, json, sys\n"
+            "l = C.CDLL(%r)\n"
+            "d = (C.c_double * 21)(); i = (C.c_int * 15)(); v = C.create_string_buffer(1024)\n"
+            "l.ref_config_load(%r.encode(), d, i, v, 1024)\n"
+            "print('CFG' + json.dumps({'d': list(d), 'i': list(i), 'vars': v.value.decode().split()}))\n") % (so, path)
+    import json
+    import sys
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("CFG")]
+    if not line:
+        return {"rejected": out.stdout.strip()}
+    r = json.loads(line[0][3:])
+    dn = ("R_specific k cv baseT bc_strength bc_inVx bc_inVy bc_inVz bc_inT viscosity density Re Pr lam depth_var frame_time dx dy dz depth _").split()
+    inn = ("bc_noslip useNormalizedParams cycles time_steps out_time_steps outdimx outdimy outdimz num_global num_local problem_dim in_fmt "
+           "out_fmt solver n_out_vars").split()
+    res = dict(zip(dn, r["d"])); res.update(zip(inn, r["i"])); res["out_vars"] = r["vars"]
+    return res
 
 
 def _sfx(dtype):

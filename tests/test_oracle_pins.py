@@ -191,3 +191,90 @@ def test_time_step_reports_divergence():
         o.set_field(O.L_CUR, v, f)
     rc, e = o.time_step(0.1, 1, 1, True)
     assert rc == 1 and e > 0.01
+
+
+# ---- the host-side loaders against the reference's own code (oracle/_ref: Common/Config.h + LinuxIO.cpp, Geometry.h) -------------
+INPUTS = os.path.join(GOLD, "inputs")
+
+
+@needs_ref
+@pytest.mark.parametrize("name", ["box_pipe_2D_config.txt", "non_uniform_pipe_2D_config.txt", "white_sea_config.txt", "heart_us_2D_config.txt"])
+def test_config_parser_is_the_reference_parser(name):
+    """Every value the reference's Config::LoadFromFile leaves behind for a config, against the Python parser (shape2d.Config; the
+    C++ one, host/Config.h, is held to the Python one in tests/test_grid_loader.py / test_host_driver.py)."""
+    from cmc_fluid_solver_amd import shape2d
+    path = os.path.join(INPUTS, name)
+    ref = O.ref_config(path)
+    assert ref is not None and "rejected" not in ref, ref
+    c = shape2d.Config(path)
+    for k in ("R_specific", "k", "cv", "baseT", "bc_strength", "bc_inT", "viscosity", "density", "Re", "Pr", "lam", "depth_var", "frame_time", "dx", "dy", "dz", "depth"):
+        assert getattr(c, k) == ref[k], (k, getattr(c, k), ref[k])
+    assert tuple(c.bc_inV) == (ref["bc_inVx"], ref["bc_inVy"], ref["bc_inVz"])
+    for k in ("cycles", "time_steps", "out_time_steps", "outdimx", "outdimy", "outdimz", "num_global", "num_local"):
+        assert getattr(c, k) == ref[k], k
+    assert bool(c.bc_noslip) == bool(ref["bc_noslip"]) and bool(c.useNormalizedParams) == bool(ref["useNormalizedParams"])
+    assert c.out_vars == ref["out_vars"]
+    assert ["2D", "3D"][ref["problem_dim"]] == c.problem_dim and ["Shape2D", "Shape3D", "SeaNetCDF"][ref["in_fmt"]] == c.in_fmt
+    assert ["NetCDF", "MultiVox"][ref["out_fmt"]] == c.out_fmt and ["Explicit", "ADI", "Stable"][ref["solver"]] == c.solver
+
+
+@needs_ref
+def test_reference_parser_rejects_what_ours_rejects(tmp_path):
+    """The shipped heart_us configs (old keys, no out_vars) and configs with a missing key: the reference prints its message and
+    exits; the Python / C++ parsers raise with the same message."""
+    from cmc_fluid_solver_amd import shape2d
+    good = open(os.path.join(INPUTS, "box_pipe_2D_config.txt")).read().replace("\r", "")
+    cases = {"no_vars": "\n".join(ln for ln in good.split("\n") if not ln.startswith("out_vars")),
+             "no_dz": "\n".join(ln for ln in good.split("\n") if not ln.startswith("grid_dz")),
+             "no_solver": "\n".join(ln for ln in good.split("\n") if not ln.startswith("solver"))}
+    for tag, text in cases.items():
+        p = str(tmp_path / (tag + ".txt"))
+        open(p, "w").write(text)
+        ref = O.ref_config(p)
+        assert "rejected" in ref, tag
+        with pytest.raises(ValueError) as ei:
+            shape2d.Config(p)
+        assert str(ei.value) in ref["rejected"], (tag, str(ei.value), ref["rejected"])
+
+
+@needs_ref
+def test_bounding_boxes_are_the_reference_ones(tmp_path):
+    """BBox2D::Build / BBox3D::Build (Geometry.h:464-480, 510-529) on the points of the fixture inputs, all frames."""
+    from cmc_fluid_solver_amd import shape2d, shape3d
+    rl = O.ref_lib()
+    pf, pi = C.POINTER(C.c_float), C.POINTER(C.c_int)
+    for name in ("box_pipe_2D_data.txt", "non_uniform_pipe_2D_data.txt", "heart_us_2D_data.txt"):
+        frames = shape2d.parse_shape2d(open(os.path.join(INPUTS, name)).read())
+        pts = [np.array([p for sh in fr["shapes"] for p in sh["points"]], np.float32) for fr in frames]
+        npts = np.array([len(p) for p in pts], np.int32)
+        xy = np.ascontiguousarray(np.concatenate(pts), np.float32)
+        out = np.zeros(4, np.float32)
+        rl.ref_bbox2d_build(len(frames), npts.ctypes.data_as(pi), xy.ctypes.data_as(pf), out.ctypes.data_as(pf))
+        g2 = shape2d.Grid2D(frames, 0.01, 0.01, 1.0, False)
+        assert tuple(np.float32(v) for v in g2.bbox) == tuple(out), name
+    rng = np.random.default_rng(5)
+    vs = [rng.uniform(-30, 50, (40, 3)), rng.uniform(-35, 45, (40, 3))]
+    tri = np.array([[0, 1, 2]])
+    path = str(tmp_path / "m.txt")
+    shape3d.write_mesh(path, [(v, tri) for v in vs])
+    frames = shape3d.parse_shape3d(open(path).read())
+    sh = shape3d.Shape3D(frames, 0.001, 0.001, 0.001, False)
+    nv = np.array([40, 40], np.int32)
+    xyz = np.ascontiguousarray(np.concatenate([fr["v"] for fr in frames]), np.float32)
+    out = np.zeros(6, np.float32)
+    rl.ref_bbox3d_build(2, nv.ctypes.data_as(pi), xyz.ctypes.data_as(pf), out.ctypes.data_as(pf))
+    assert tuple(np.float32(v) for v in sh.bbox) == tuple(out)
+
+
+@needs_ref
+def test_depth_resampling_is_the_reference_one():
+    """DepthInfo3D(nx, ny, info) (Geometry.h:429-441): the `d` variable of a SeaNetCDF run and the depth lookup of the loader."""
+    from cmc_fluid_solver_amd import seanetcdf
+    rl = O.ref_lib()
+    pf = C.POINTER(C.c_float)
+    rng = np.random.default_rng(6)
+    src = rng.uniform(-200, 100, (301, 722)).astype(np.float32)
+    for nx, ny in ((150, 100), (160, 96), (301, 722), (7, 1000)):
+        out = np.zeros((nx, ny), np.float32)
+        rl.ref_depth_resample(nx, ny, 301, 722, src.ctypes.data_as(pf), out.ctypes.data_as(pf))
+        assert np.array_equal(out, seanetcdf.resample_depths(src, nx, ny))
