@@ -423,7 +423,7 @@ def test_slabs_reduced_interface_x_solve(built, nranks, dtype):
     grp.close()
 
 
-@pytest.mark.parametrize("dimx,nranks,onchip", [(64, 2, True), (64, 4, True), (96, 3, True), (128, 2, True), (64, 3, False), (70, 2, False)])
+@pytest.mark.parametrize("dimx,nranks,onchip", [(64, 2, True), (64, 4, True), (96, 3, True), (128, 2, True), (64, 8, True), (72, 3, True), (64, 3, False), (70, 2, False)])
 def test_slab_interface_words_from_the_partition_kernel(built, dimx, nranks, onchip):
     """Slabs of whole 16-plane chunks take their 18 interface words per line from a first pass of the X partition kernel
     (rows and chunk elimination on chip) instead of the thread-per-line walk; other slab heights keep the walk.  One merged
@@ -467,15 +467,17 @@ def test_slab_interface_words_from_the_partition_kernel(built, dimx, nranks, onc
     assert vec_rel(full, ref_cur) <= TOL_STEPS and rel(full[3], ref_cur[3]) <= TOL_STEPS
 
 
-def test_slabs_default_is_the_reduced_interface_solve(built):
-    """FS3D_SWEEP_AUTO on slabs: partition kernels for Y and Z, the reduced-interface X solve; against one context (AUTO)."""
+@pytest.mark.parametrize("nslabs", [4, 8])
+def test_slabs_default_is_the_reduced_interface_solve(built, nslabs):
+    """FS3D_SWEEP_AUTO on slabs: partition kernels for Y and Z, the reduced-interface X solve; against one context (AUTO).
+    (8 slabs of the 64^3 box = the self-check bench.py --gpus 8 runs before it times anything.)"""
     g = grids.box(64, h=1.0 / 63)
     params = capi.fluid_params(np.float32, *PARAMS)
     s = capi.Solver(g, params, np.float32)
     for i in range(2):
         s.UpdateBoundaries(); s.TimeStep(DT, 4, 2, True)
     ref = s.download_layer(capi.LAYER_CUR); s.close()
-    grp = capi.LocalGroup(g, params, 4, np.float32)
+    grp = capi.LocalGroup(g, params, nslabs, np.float32)
 
     def steps(r, sv):
         for i in range(2):
@@ -483,7 +485,7 @@ def test_slabs_default_is_the_reduced_interface_solve(built):
         return sv.download_layer(capi.LAYER_CUR), sv.last_sweep_kernels()
     res = grp.run(steps)
     assert res[0][1]["Y"] == "part" and res[0][1]["Z"] == "part" and "reduced-interface" in res[0][1]["X"]
-    full = [np.concatenate([res[r][0][v] for r in range(4)], axis=0) for v in range(4)]
+    full = [np.concatenate([res[r][0][v] for r in range(nslabs)], axis=0) for v in range(4)]
     assert vec_rel(full, ref) <= TOL_STEPS and rel(full[3], ref[3]) <= TOL_STEPS
     grp.close()
 
