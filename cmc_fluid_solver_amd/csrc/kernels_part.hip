@@ -593,7 +593,9 @@ static bool part_launch_xy(fs3d_ctx *c, const SweepParams<R> &p)
 {
     const int n_o = DIR == 0 ? p.dimy : (p.o_count ? p.o_count : p.dimx);
     const int n_tiles = (p.dimz + LT - 1) / LT;
-    const size_t lds = ((size_t)NCH * M * LT + (size_t)(PART_EXW + (NCH > 16 ? 4 : 0)) * NCH * LT) * sizeof(R);
+    // FS3D_PART_LDSPAD (kernel experiments): more dynamic LDS than needed, to hold the workgroups per CU down
+    static const size_t lds_pad = getenv("FS3D_PART_LDSPAD") ? (size_t)atoi(getenv("FS3D_PART_LDSPAD")) : 0;
+    const size_t lds = ((size_t)NCH * M * LT + (size_t)(PART_EXW + (NCH > 16 ? 4 : 0)) * NCH * LT) * sizeof(R) + lds_pad;
     static std::atomic<unsigned long long> attr_set{0};
     const unsigned long long dev_bit = 1ull << (c->device & 63);
     if (!(attr_set.load() & dev_bit)) {
