@@ -37,7 +37,7 @@ struct SweepParams {
     const uint8_t *dead;        // per line of the sweep direction: 1 = no cell of the line is on a segment or NODE_IN (partition kernels)
     const R *node_;             // node boundary values (v.x, v.y, v.z, T), field v at + v*nstride
     R *scr_;                    // LINE kernel scratch: c'_uvw, c'_T, d'_U, d'_V, d'_W, d'_T at + v*nstride
-    long long nstride;          // = number of owned cells
+    long long nstride;          // elements between consecutive fields of node_ / scr_ (>= number of owned cells)
     __host__ __device__ const R *cur(int v) const { return cur_ + v * fstride; }
     __host__ __device__ const R *temp(int v) const { return temp_ + v * fstride; }
     __host__ __device__ R *next(int v) const { return next_ + v * fstride; }
@@ -77,9 +77,11 @@ struct fs3d_ctx {
     bool have_params = false, have_nodes = false;
     size_t esize = 4;
     long long plane = 0, ncell = 0;
+    long long nstride = 0;      // elements between the fields of the node-value / scratch arrays: ncell + padding
     // 5 layer buffers (cur,temp,half,next + spare temp for double-buffering)
-    void *lay[5] = {};          // one allocation per layer buffer: 4 fields of fstride elements
-    long long fstride = 0;      // ncell + 2*plane
+    void *lay[5] = {};          // one allocation per layer buffer: 4 fields of fstride elements (lay_raw + a per-layer skew)
+    void *lay_raw[5] = {};      // what hipMalloc returned
+    long long fstride = 0;      // ncell + 2*plane + padding (the fields / layers of one cell must not share their low address bits)
     int slot[4] = {0, 1, 2, 3}; // layer id -> buffer
     int spare = 4;
     uint16_t *code = nullptr;

@@ -230,11 +230,28 @@ extern "C" fs3d_status fs3d_create(fs3d_ctx **out, int device, fs3d_precision pr
     CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     // every field = haloSize + dimx*dimy*dimz + haloSize elements, data at +haloSize
     // (TimeLayer3D.h:354, GPUplan.h:79-108), zero-initialised
-    c->fstride = c->ncell + 2 * c->plane;
+    // A sweep streams 16 arrays at once (4 fields of cur, temp, next, temp_out) at the same cell offset.  With power-of-two
+    // grids the field stride and the allocation granularity put all 16 on the same low address bits (the same memory channel):
+    // fields are padded and layers skewed against each other (FS3D_FIELD_PAD elements, FS3D_LAYER_SKEW bytes: experiments).
+    // Measured (256^3 fp32, tools/pad_sweep.py, profiles/r2_padding.txt): 2338 -> 2770 Mcells/s; any pad of 576 .. 2112 elements does it.
+    long long fpad = 576;                                      // 9 x 256 bytes in fp32
+    size_t skew = 4864;                                        // 19 x 256 bytes per layer
+    if (const char *e = getenv("FS3D_FIELD_PAD")) fpad = atoll(e) / 4 * 4;
+    if (const char *e = getenv("FS3D_LAYER_SKEW")) skew = (size_t)atoll(e) / 256 * 256;
+    if (fpad < 0) fpad = 0;
+    c->fstride = c->ncell + 2 * c->plane + fpad;
     const size_t lbytes = (size_t)4 * c->fstride * c->esize;
-    for (int l = 0; l < 5; l++) { CK(hipMalloc(&c->lay[l], lbytes)); CK(hipMemsetAsync(c->lay[l], 0, lbytes, c->stream)); }
-    CK(hipMalloc((void **)&c->code, (size_t)c->ncell * sizeof(uint16_t)));
-    CK(hipMalloc(&c->node, (size_t)4 * c->ncell * c->esize));
+    for (int l = 0; l < 5; l++) {
+        CK(hipMalloc(&c->lay_raw[l], lbytes + 5 * skew));
+        c->lay[l] = (char *)c->lay_raw[l] + (size_t)l * skew;
+        CK(hipMemsetAsync(c->lay[l], 0, lbytes, c->stream));
+    }
+    // the 4 node-value fields and the 6 row fields of the exact kernels' scratch: padded the same way
+    c->nstride = c->ncell + (getenv("FS3D_FIELD_PAD") ? fpad : 832);
+    CK(hipMalloc((void **)&c->code, (size_t)c->nstride * sizeof(uint16_t)));
+    CK(hipMemsetAsync(c->code, 0, (size_t)c->nstride * sizeof(uint16_t), c->stream));
+    CK(hipMalloc(&c->node, (size_t)4 * c->nstride * c->esize));
+    CK(hipMemsetAsync(c->node, 0, (size_t)4 * c->nstride * c->esize, c->stream));
     c->red_blocks = 1024;
     CK(hipMalloc((void **)&c->red_buf, sizeof(double) * 2 * (c->red_blocks + 1)));
     CK(hipHostMalloc((void **)&c->red_host, sizeof(double) * 2, hipHostMallocDefault));
@@ -253,7 +270,7 @@ extern "C" void fs3d_destroy(fs3d_ctx *c)
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     fs3d_comm_destroy(c);
-    for (int l = 0; l < 5; l++) if (c->lay[l]) hipFree(c->lay[l]);
+    for (int l = 0; l < 5; l++) if (c->lay_raw[l]) hipFree(c->lay_raw[l]);
     if (c->redo) hipFree(c->redo);
     for (int i = 0; i < 2; i++) if (c->seg_carry[i]) hipFree(c->seg_carry[i]);
     if (c->code) hipFree(c->code);
@@ -442,7 +459,7 @@ static fs3d_status upload_nodes_impl(fs3d_ctx *c, const uint8_t *type, const uin
         }
     }
     for (int v = 0; v < 4; v++)
-        HIPCHK(c, hipMemcpy((R *)c->node + (size_t)v * c->ncell, nv[v].data(), (size_t)c->ncell * sizeof(R), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy((R *)c->node + (size_t)v * c->nstride, nv[v].data(), (size_t)c->ncell * sizeof(R), hipMemcpyHostToDevice));
     if (c->bnd_idx) { hipFree(c->bnd_idx); c->bnd_idx = nullptr; }
     for (int v = 0; v < 4; v++) if (c->bnd_val[v]) { hipFree(c->bnd_val[v]); c->bnd_val[v] = nullptr; }
     c->n_bnd = (int)bidx.size();
@@ -492,7 +509,7 @@ extern "C" fs3d_status fs3d_init_layers_from_nodes(fs3d_ctx *c)
     for (int l = 0; l < 4; l++) c->slot[l] = l;
     c->spare = 4;
     for (int v = 0; v < 4; v++)
-        HIPCHK(c, hipMemcpyAsync(fptr(c, c->slot[FS3D_LAYER_CUR], v), (char *)c->node + (size_t)v * c->ncell * c->esize,
+        HIPCHK(c, hipMemcpyAsync(fptr(c, c->slot[FS3D_LAYER_CUR], v), (char *)c->node + (size_t)v * c->nstride * c->esize,
                                  (size_t)c->ncell * c->esize, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return FS3D_OK;
@@ -545,7 +562,7 @@ static void fill_params(fs3d_ctx *c, SweepParams<R> &p, int dir, double dt_, int
     p.cur_ = fld<R>(c, b_cur, 0); p.temp_ = fld<R>(c, b_temp, 0);
     p.next_ = fld<R>(c, b_next, 0); p.temp_out_ = fld<R>(c, b_tout, 0);
     p.fstride = c->fstride;
-    p.node_ = (const R *)c->node; p.scr_ = (R *)c->scr; p.nstride = c->ncell;
+    p.node_ = (const R *)c->node; p.scr_ = (R *)c->scr; p.nstride = c->nstride;
     p.code = c->code;
     p.dead = c->dead[dir];
     // every constant below is evaluated in FTYPE exactly as the reference writes it
@@ -578,8 +595,8 @@ static void fill_params(fs3d_ctx *c, SweepParams<R> &p, int dir, double dt_, int
 static fs3d_status ensure_scratch(fs3d_ctx *c)
 {
     if (c->scr) return FS3D_OK;
-    HIPCHK(c, hipMalloc(&c->scr, (size_t)6 * c->ncell * c->esize));
-    c->scr_bytes = (size_t)6 * c->ncell * c->esize;
+    HIPCHK(c, hipMalloc(&c->scr, (size_t)6 * c->nstride * c->esize));
+    c->scr_bytes = (size_t)6 * c->nstride * c->esize;
     return FS3D_OK;
 }
 

@@ -441,7 +441,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_sweep_pipe(SweepParams<R> p, int
         ck.ssb = (unsigned)(ss * (long long)sizeof(R));
         const int lc = l < la_len ? lane : la_len - 1 - tile_id * 64;   // clamp lanes past the lane axis
         ck.vob = (unsigned)(DIR == 2 ? lc * p.dimz : lc) * (unsigned)sizeof(R);
-        ck.fbytes = (unsigned)((p.nstride + 2 * p.plane) * (long long)sizeof(R));
+        ck.fbytes = (unsigned)(p.fstride * (long long)sizeof(R));                  // a whole field: halo plane, cells, halo plane (+ padding)
         ck.fsb = (unsigned)(p.fstride * (long long)sizeof(R));
         ck.vob_st = l < la_len ? ck.vob : BUF_OOB;
     }
@@ -1058,7 +1058,7 @@ bool launch_sweep_pipe<double>(fs3d_ctx *c, int dir, const SweepParams<double> &
 template <typename R>
 static bool pipe_scratch(fs3d_ctx *c, size_t elems)
 {
-    const size_t bytes = std::max(elems, (size_t)6 * (size_t)c->ncell) * sizeof(R);
+    const size_t bytes = std::max(elems, (size_t)6 * (size_t)c->nstride) * sizeof(R);
     if (c->scr && c->scr_bytes >= bytes) return true;
     if (c->scr) { hipStreamSynchronize(c->stream); hipFree(c->scr); c->scr = nullptr; c->scr_bytes = 0; }
     if (hipMalloc(&c->scr, bytes) != hipSuccess) return false;
