@@ -5,7 +5,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cmc_fluid_solver_amd import capi, grids
 
-for dims in ((256, 256, 256), (256, 248, 256), (256, 256, 248), (256, 240, 256), (248, 256, 256), (256, 264, 256)):
+for dims in ((256, 256, 256), (256, 256, 256), (256, 248, 256), (248, 256, 256), (256, 252, 256), (252, 256, 256)):
     g = grids.box(*dims, h=1.0 / 255)
     s = capi.Solver(g, capi.fluid_params(np.float32, 200.0, 0.72, 1.4), np.float32)
     for i in range(2):
