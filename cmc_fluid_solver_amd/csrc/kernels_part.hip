@@ -608,7 +608,10 @@ static bool part_launch_xy(fs3d_ctx *c, const SweepParams<R> &p)
     // workgroup order: 32-line tiles run the lane tiles of one row/plane on consecutive workgroups (the 128-byte pieces of a
     // row are then fetched together: 512^3 X 2.93 -> 2.71 ms, Y 2.18 -> 2.10), 64-line tiles the rows/planes of one lane tile
     static const int order_env = getenv("FS3D_PART_ORDER") ? atoi(getenv("FS3D_PART_ORDER")) : -1;   // kernel experiments
-    const int order = order_env >= 0 ? order_env : (LT == 32 ? 1 : 0);
+    // 32-line tiles, two workgroups per CU: the second workgroup of every CU starts ~16 us late, so that the two do not load,
+    // solve and store at the same time (tools/ab_tiles.py, interleaved on one box: 64 lines 6.12 ms per step, 32 lines 5.81,
+    // 32 lines with the late start 5.63-5.66).  Few workgroups (thin slabs) and 512-cell lines: lane tiles fastest.
+    const int order = order_env >= 0 ? order_env : (LT == 32 ? (((long long)n_o * n_tiles < 1024 || NCH == 32) ? 1 : 0) | 0x40 | (4 << 8) : 0);
     hipLaunchKernelGGL((k_sweep_part<R, DIR, M, NCH, WPS, LT, PF, XB, OPF, KT>), dim3((unsigned)(n_o * n_tiles)), dim3(LT * NCH), lds, c->stream, p, n_o, n_tiles, order);
     return true;
 }
@@ -653,9 +656,10 @@ static bool part_dispatch_xy(fs3d_ctx *c, const SweepParams<R> &p)
             // thin slabs (a 32-plane x-slab of the 256^3 box: 32 x 4 workgroups of 64 lines for 256 CUs): 32-line
             // workgroups, twice as many
             const int n_o = DIR == 0 ? p.dimy : p.dimx;
-            if (variant == 7 || (long long)n_o * ((p.dimz + 63) / 64) < 256) return part_launch_xy<R, DIR, 16, 16, 4, 32>(c, p);
-            // 64 lines x 16 chunks: 256-byte row pieces (measured: 1.1x the speed of 128-byte pieces in the Y sweep, 1.2x in X)
-            return part_launch_xy<R, DIR, 16, 16, 4, 64>(c, p);
+            // 64 lines x 16 chunks (one workgroup of 1024 threads per CU, 256-byte row pieces) was the default until the layer fields
+            // were padded; since then two 32-line workgroups per CU are faster (their phases overlap inside the CU)
+            if (variant == 64) return part_launch_xy<R, DIR, 16, 16, 4, 64>(c, p);
+            return part_launch_xy<R, DIR, 16, 16, 4, 32>(c, p);
         }
         if (n <= 512) return part_launch_xy<R, DIR, 16, 32, 4, 32>(c, p);
     }
