@@ -149,6 +149,8 @@ class Hdf5File:
         if btree == UNDEF:
             return out
         for offs, addr, size, mask in self._chunks(btree, rank):
+            if self.base + addr + size > len(d):
+                raise Hdf5Error("chunk data past the end of the file")
             raw = d[self.base + addr:self.base + addr + size]
             for k, f in reversed(list(enumerate(filters))):     # undo the pipeline back to front
                 if mask & (1 << k):

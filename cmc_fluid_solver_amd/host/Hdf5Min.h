@@ -176,6 +176,7 @@ public:
         std::vector<Chunk> cs;
         chunks(btree, rank, cs);
         for (const Chunk &c : cs) {
+            if (c.addr + base_ > d_.size() || c.size > d_.size() - (size_t)(c.addr + base_)) throw std::runtime_error("HDF5: chunk data past the end of the file");
             std::vector<unsigned char> raw(d_.begin() + (size_t)(c.addr + base_), d_.begin() + (size_t)(c.addr + base_) + c.size);
             for (int k = (int)r.filters.size() - 1; k >= 0; k--) {     // undo the pipeline back to front
                 if (c.mask & (1u << k)) continue;
