@@ -611,7 +611,9 @@ static bool part_launch_xy(fs3d_ctx *c, const SweepParams<R> &p)
     // 32-line tiles, two workgroups per CU: the second workgroup of every CU starts ~16 us late, so that the two do not load,
     // solve and store at the same time (tools/ab_tiles.py, interleaved on one box: 64 lines 6.12 ms per step, 32 lines 5.81,
     // 32 lines with the late start 5.63-5.66).  Few workgroups (thin slabs) and 512-cell lines: lane tiles fastest.
-    const int order = order_env >= 0 ? order_env : (LT == 32 ? (((long long)n_o * n_tiles < 1024 || NCH == 32) ? 1 : 0) | 0x40 | (4 << 8) : 0);
+    // (the late start only where it was measured: 512-thread workgroups, two per CU, at least two generations of them)
+    const bool late = LT == 32 && NCH == 16 && M == 16 && (long long)n_o * n_tiles >= 1024;
+    const int order = order_env >= 0 ? order_env : (LT == 32 ? (((long long)n_o * n_tiles < 1024 || NCH == 32) ? 1 : 0) | (late ? 0x40 | (4 << 8) : 0) : 0);
     hipLaunchKernelGGL((k_sweep_part<R, DIR, M, NCH, WPS, LT, PF, XB, OPF, KT>), dim3((unsigned)(n_o * n_tiles)), dim3(LT * NCH), lds, c->stream, p, n_o, n_tiles, order);
     return true;
 }
