@@ -5,6 +5,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 code = ("import sys; sys.path.insert(0, %r); import part_check as P; from cmc_fluid_solver_amd import capi\n"
         "P.timing(256, capi.SWEEP_AUTO, reps=12); P.timing(256, capi.SWEEP_AUTO, reps=16)") % HERE
 cfgs = [("64 lines", 64, 0), ("32 lines", 0, 0), ("32 lines, 2nd wg +8us", 0, 0x0240), ("32 lines, 2nd wg +16us (default)", 0, None), ("32 lines, 2nd wg +24us", 0, 0x0640)]
+if os.environ.get("AB_ORDER1"):
+    cfgs = [("32 lines, +16us (default)", 0, None), ("same, lane tiles fastest", 0, 0x0441), ("+12us", 0, 0x0340), ("+20us", 0, 0x0540)]
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 acc = {c[0]: [] for c in cfgs}
 for r in range(rounds):
