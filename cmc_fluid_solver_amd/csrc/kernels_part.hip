@@ -156,8 +156,12 @@ __global__ void __launch_bounds__(LT * NCH, WPS) k_sweep_part(SweepParams<R> p, 
         const int grp = (order & 0x20) ? (int)((blockIdx.x >> 3) % 3) : (int)((blockIdx.x >> 3) & 1);
         for (int w = grp * (order >> 8); w > 0; w--) __builtin_amdgcn_s_sleep(127);
     }
-    if ((order & 0x40) && blockIdx.x >= 256 && blockIdx.x < 512)      // two workgroups per CU: the second one of every CU starts late
-        for (int w = order >> 8; w > 0; w--) __builtin_amdgcn_s_sleep(127);
+    if (order & 0x40) {                                   // several workgroups per CU: the k-th one of every CU starts k delays late
+        constexpr int WPC = 1024 / (LT * NCH) < 2 ? 2 : 1024 / (LT * NCH);
+        const int slot = (int)(blockIdx.x >> 8);
+        if (slot > 0 && slot < WPC)
+            for (int w = slot * (order >> 8); w > 0; w--) __builtin_amdgcn_s_sleep(127);
+    }
     PSTAMP(0);
 
     // XCD-aware block order (speed only): blocks b, b+8, .. share an XCD under round-robin dispatch; give each XCD a
@@ -613,7 +617,9 @@ static bool part_launch_xy(fs3d_ctx *c, const SweepParams<R> &p)
     // 32 lines with the late start 5.63-5.66).  Few workgroups (thin slabs) and 512-cell lines: lane tiles fastest.
     // (the late start only where it was measured: 512-thread workgroups, two per CU, at least two generations of them)
     const bool late = LT == 32 && NCH == 16 && M == 16 && (long long)n_o * n_tiles >= 1024;
-    const int order = order_env >= 0 ? order_env : (LT == 32 ? (((long long)n_o * n_tiles < 1024 || NCH == 32) ? 1 : 0) | (late ? 0x40 | (4 << 8) : 0) : 0);
+    static const int late_slab = getenv("FS3D_PART_LATE_SLAB") ? atoi(getenv("FS3D_PART_LATE_SLAB")) : 0;   // experiment: slab kernels (XB != 0), delay units
+    int order = order_env >= 0 ? order_env : (LT == 32 ? (((long long)n_o * n_tiles < 1024 || NCH == 32) ? 1 : 0) | (late ? 0x40 | (4 << 8) : 0) : 0);
+    if (XB != 0 && late_slab > 0 && LT * NCH <= 512 && (long long)n_o * n_tiles >= 512) order |= 0x40 | (late_slab << 8);
     hipLaunchKernelGGL((k_sweep_part<R, DIR, M, NCH, WPS, LT, PF, XB, OPF, KT>), dim3((unsigned)(n_o * n_tiles)), dim3(LT * NCH), lds, c->stream, p, n_o, n_tiles, order);
     return true;
 }
