@@ -513,3 +513,30 @@ def test_halo_planes_beside_the_interior_sweep(built, nranks):
     for a, b in zip(out[1][0], out[0][0]):
         assert np.array_equal(a, b)
     assert out[1][1] == out[0][1]
+
+
+def test_results_do_not_depend_on_layout_padding_or_workgroup_schedule(built, tmp_path):
+    """Field padding / layer skew (fs3d_create) and the workgroup order / late start of the X/Y kernels are speed knobs: the fields
+    after two steps are bit-identical whatever they are set to (each setting in a process of its own: the knobs are read once)."""
+    import subprocess
+    import sys
+    code = ("import sys, hashlib, numpy as np\n"
+            "from cmc_fluid_solver_amd import capi, grids\n"
+            "g = grids.box_with_obstacle(136, 150, 64, h=0.01)\n"
+            "s = capi.Solver(g, capi.fluid_params(np.float32, 200.0, 0.72, 1.4), np.float32)\n"
+            "for i in range(2):\n"
+            "    s.UpdateBoundaries(); s.TimeStep(0.1, 2, 2, True)\n"
+            "h = hashlib.sha256()\n"
+            "for a in s.download_layer(capi.LAYER_CUR): h.update(np.ascontiguousarray(a).tobytes())\n"
+            "print('HASH', h.hexdigest(), s.last_sweep_kernels())\n")
+    outs = {}
+    for tag, env in (("default", {}), ("no padding", {"FS3D_FIELD_PAD": "0", "FS3D_LAYER_SKEW": "0"}), ("big padding", {"FS3D_FIELD_PAD": "4164", "FS3D_LAYER_SKEW": "66048"}),
+                     ("rows fastest, no late start", {"FS3D_PART_ORDER": "0"}), ("tiles fastest, late start", {"FS3D_PART_ORDER": str(1 | 0x40 | (3 << 8))}),
+                     ("64-line tiles", {"FS3D_PART_VARIANT": "64"})):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("HASH")]
+        assert line, (tag, r.stdout[-300:], r.stderr[-300:])
+        outs[tag] = line[0]
+    assert "'X': 'part'" in outs["default"]
+    assert len(set(outs.values())) == 1, outs
