@@ -540,3 +540,44 @@ def test_results_do_not_depend_on_layout_padding_or_workgroup_schedule(built, tm
         outs[tag] = line[0]
     assert "'X': 'part'" in outs["default"]
     assert len(set(outs.values())) == 1, outs
+
+
+@pytest.mark.parametrize("nranks", [2, 4, 8])
+def test_slab_kernels_of_wide_grids(built, nranks):
+    """Slabs of a grid wide enough for the 64-line slab kernels (dimy x dimz/64 >= 512 tiles: what a 256^3 run on 2, 4, 8 GPUs launches:
+    128-, 64- and 32-plane slabs): one merged X sweep on a seeded state and one step against ONE context."""
+    from cmc_fluid_solver_amd.slab import slab_range
+    g = grids.box_with_obstacle(256, 256, 128, h=0.004)
+    params = capi.fluid_params(np.float32, *PARAMS)
+    base = [np.ascontiguousarray(a, np.float32) for a in (g.vx, g.vy, g.vz, g.T)]
+    cur, tmp = grids.perturb(base, seed=7), grids.perturb(base, seed=8)
+    s = capi.Solver(g, params, np.float32)
+    s.upload_layer(capi.LAYER_CUR, cur); s.upload_layer(capi.LAYER_TEMP, tmp)
+    s.sweep(0, DT, capi.LAYER_CUR, capi.LAYER_TEMP, capi.LAYER_NEXT, merge=True)
+    ref_next, ref_temp = s.download_layer(capi.LAYER_NEXT), s.download_layer(capi.LAYER_TEMP)
+    s.close()
+    s = capi.Solver(g, params, np.float32)
+    s.UpdateBoundaries(); s.TimeStep(DT, 2, 2, True)
+    ref_cur = s.download_layer(capi.LAYER_CUR); s.close()
+    grp = capi.LocalGroup(g, params, nranks, np.float32)
+
+    def work(r, sv):
+        x0, x1 = slab_range(g.dimx, r, nranks)
+        sv.upload_layer(capi.LAYER_CUR, [f[x0:x1] for f in cur]); sv.upload_layer(capi.LAYER_TEMP, [f[x0:x1] for f in tmp])
+        sv.sweep(0, DT, capi.LAYER_CUR, capi.LAYER_TEMP, capi.LAYER_NEXT, merge=True)
+        return sv.last_sweep_kernels()["X"], sv.download_layer(capi.LAYER_NEXT), sv.download_layer(capi.LAYER_TEMP)
+    res = grp.run(work)
+    grp.close()
+    assert all("on-chip" in r[0] for r in res), [r[0] for r in res]
+    for v in range(4):
+        nx = np.concatenate([r[1][v] for r in res], axis=0); tp = np.concatenate([r[2][v] for r in res], axis=0)
+        assert rel(nx, ref_next[v]) <= TOL_SWEEP and rel(tp, ref_temp[v]) <= TOL_SWEEP, "field %d: %.2e / %.2e" % (v, rel(nx, ref_next[v]), rel(tp, ref_temp[v]))
+    grp = capi.LocalGroup(g, params, nranks, np.float32)
+
+    def step(r, sv):
+        sv.UpdateBoundaries(); sv.TimeStep(DT, 2, 2, True)
+        return sv.download_layer(capi.LAYER_CUR)
+    res = grp.run(step)
+    grp.close()
+    full = [np.concatenate([r[v] for r in res], axis=0) for v in range(4)]
+    assert vec_rel(full, ref_cur) <= TOL_STEPS and rel(full[3], ref_cur[3]) <= TOL_STEPS
