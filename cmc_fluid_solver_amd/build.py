@@ -64,6 +64,17 @@ def build_variant(name, extra_flags, source="kernels_part.hip"):
 
 
 DRIVER = os.path.join(HERE, "fs3d_run")
+DRIVER2D = os.path.join(HERE, "fs2d_run")
+
+
+def build_driver2d(force=False):
+    """The CPU-only 2D command line (host/fs2d_run.cpp: Stable solver over a Grid2D); g++, no GPU library."""
+    host = os.path.join(HERE, "host")
+    deps = [os.path.join(host, f) for f in ("fs2d_run.cpp", "Stable2D.h", "Shape2D.h", "Config.h", "AdiSolver3D_hip.h")]
+    if force or _stale(DRIVER2D, deps):
+        subprocess.check_call([os.environ.get("CXX", "g++"), "-std=c++17", "-O2", "-Wall", "-ffp-contract=off", "-I" + os.path.join(HERE, "..", "include"),
+                               os.path.join(host, "fs2d_run.cpp"), "-o", DRIVER2D])
+    return DRIVER2D
 
 
 def build_driver(force=False, verbose=False):

@@ -51,11 +51,11 @@ def parse_shape2d(text):
             for _ in range(npts):
                 x, y = _read_point(next(it).split())
                 pts.append((F(x * GRID_SCALE_FACTOR), F(y * GRID_SCALE_FACTOR)))
-            word = next(it)
-            active = word[0] == "M"
+            word = next(it).split()                                # "Passive" | "Motion" + "vx vy" on the same or on the next line
+            active = word[0][0] == "M"
             vx, vy = F(0), F(0)
             if active:
-                vx, vy = _read_point(next(it).split())
+                vx, vy = _read_point(word[1:3] if len(word) >= 3 else next(it).split())
             vel = [(F(vx * GRID_SCALE_FACTOR), F(vy * GRID_SCALE_FACTOR)) for _ in range(npts)]
             shapes.append({"points": pts, "vel": vel, "active": active})
         frames.append({"duration": float(dur), "shapes": shapes})
