@@ -81,7 +81,7 @@ def build_driver(force=False, verbose=False):
     """The C++ command-line driver (host/fs3d_run.cpp) above the C ABI; g++, links libfs3d_hip.so."""
     build(force=False, verbose=verbose)
     host = os.path.join(HERE, "host")
-    deps = [os.path.join(host, f) for f in ("fs3d_run.cpp", "AdiSolver3D_hip.h", "Config.h", "Shape2D.h", "Shape3D.h", "SeaNetCDF.h", "Hdf5Min.h", "NetCDF3.h")] + [LIB]
+    deps = [os.path.join(host, f) for f in ("fs3d_run.cpp", "AdiSolver3D_hip.h", "Config.h", "Shape2D.h", "Shape3D.h", "SeaNetCDF.h", "Hdf5Min.h", "NetCDF3.h", "GridImage.h")] + [LIB]
     if force or _stale(DRIVER, deps):
         cmd = [os.environ.get("CXX", "g++"), "-std=c++17", "-O2", "-Wall", "-I" + os.path.join(HERE, "..", "include"),
                os.path.join(host, "fs3d_run.cpp"), "-o", DRIVER, "-L" + HERE, "-lfs3d_hip", "-lz", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"]

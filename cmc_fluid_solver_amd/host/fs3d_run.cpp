@@ -28,6 +28,7 @@
 #include "Shape2D.h"
 #include "Shape3D.h"
 #include "SeaNetCDF.h"
+#include "GridImage.h"
 
 // what the time loop and the result header need from the geometry (Grid3D::GetFramesNum / GetCycleLength / GetFrame / GetBBox)
 struct RunGeom {
@@ -45,7 +46,7 @@ static int run_slabs(const fs3d::Grid3D<FTYPE> &grid, const RunGeom &geo, const 
 
 template <typename FTYPE>
 static int run(const std::string &data, const std::string &prefix, const fs3d::Config &cfg, bool align, int device, long max_steps, const std::string &grid_only, bool csv,
-               int nslabs, bool same_device)
+               int nslabs, bool same_device, bool grid_images)
 {
     using namespace fs3d;
     Grid3D<FTYPE> grid;
@@ -75,6 +76,7 @@ static int run(const std::string &data, const std::string &prefix, const fs3d::C
     for (uint8_t t : grid.type) inside += t == NODE_IN;
     std::printf("NODE_IN points = %f of total %f, volume = %f\n", inside, (double)grid.dimx * grid.dimy * grid.dimz,
                 inside * grid.dx * grid.dy * grid.dz);                                          // :170
+    if (grid_images) OutputGridImages(grid, prefix + "_grid_3d");                             // FluidSolver3D.cpp:152-153 (there: always)
     if (!grid_only.empty()) {
         FILE *f = std::fopen(grid_only.c_str(), "wb");
         if (!f) throw std::runtime_error("cannot create " + grid_only);
@@ -267,7 +269,7 @@ static int run_slabs(const fs3d::Grid3D<FTYPE> &grid, const RunGeom &geo, const 
 int main(int argc, char **argv)
 {
     if (argc < 4) {
-        std::printf("Usage: %s <input data> <output prefix> <config file> [align] [GPU [n]] [double] [--steps N] [--grid-only FILE]\n", argv[0]);
+        std::printf("Usage: %s <input data> <output prefix> <config file> [align] [GPU [n]] [double] [--steps N] [--grid-only FILE] [--grid-images]\n", argv[0]);
         return 0;
     }
     try {
@@ -277,7 +279,7 @@ int main(int argc, char **argv)
         if (cfg.in_fmt != "Shape2D" && cfg.in_fmt != "Shape3D" && cfg.in_fmt != "SeaNetCDF") throw std::runtime_error("in_fmt " + cfg.in_fmt + ": unknown input format");
         if (cfg.in_fmt != "Shape2D" && !(cfg.frame_time > 0)) throw std::runtime_error("must specify frame time!");   // the cycle length of a Shape3D run (Grid3D.cpp:303-309)
         if (cfg.solver != "ADI") throw std::runtime_error("solver " + cfg.solver + " is not implemented (the reference implements ADI only)");
-        bool align = false, dbl = false, csv = false, same_device = false;
+        bool align = false, dbl = false, csv = false, same_device = false, grid_images = false;
         int nslabs = 1;
         int device = 0;
         long max_steps = -1;
@@ -293,10 +295,11 @@ int main(int argc, char **argv)
             else if (s == "--grid-only" && a + 1 < argc) grid_only = argv[++a];
             else if (s == "blocking") { if (a + 1 < argc) a++; }
             else if (s == "CSV") csv = true;
+            else if (s == "--grid-images") grid_images = true;       // <prefix>_grid_3d/<k>.bmp: the node types, one image per z-slice
             // transpose, decompose: accepted, no effect
         }
-        return dbl ? run<double>(argv[1], argv[2], cfg, align, device, max_steps, grid_only, csv, nslabs, same_device)
-                   : run<float>(argv[1], argv[2], cfg, align, device, max_steps, grid_only, csv, nslabs, same_device);
+        return dbl ? run<double>(argv[1], argv[2], cfg, align, device, max_steps, grid_only, csv, nslabs, same_device, grid_images)
+                   : run<float>(argv[1], argv[2], cfg, align, device, max_steps, grid_only, csv, nslabs, same_device, grid_images);
     } catch (std::exception &e) {
         std::fprintf(stderr, "\n\nCaught exception:\n%s\n\nTerminating...\n", e.what());     // FluidSolver3D.cpp:313-318
         return -1;

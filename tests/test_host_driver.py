@@ -65,6 +65,24 @@ def test_cpp_loader_equals_python_loader(driver, case, prec, tmp_path):
         assert np.array_equal(g[name], np.asarray(getattr(nodes, name), dt)), name
 
 
+def test_grid_images(driver, tmp_path):
+    """--grid-images: Grid3D::OutputImage, one 24-bit BMP of the node types per z-slice (Grid3D.cpp:1112-1173)."""
+    data, cfgf = (os.path.join(INPUTS, f) for f in CASES["non_uniform_pipe"])
+    prefix = str(tmp_path / "img")
+    subprocess.run([driver, data, prefix, cfgf, "align", "--grid-images", "--grid-only", str(tmp_path / "g.bin")], check=True, capture_output=True)
+    nodes, cfg, _ = shape2d.load_case(data, cfgf, align=True)
+    nx, ny, nz = nodes.shape
+    assert sorted(os.listdir(prefix + "_grid_3d"), key=lambda s: int(s[:-4])) == ["%d.bmp" % k for k in range(nz)]
+    colour = {0: (245, 73, 69), 1: (0, 0, 0), 2: (255, 255, 255), 3: (241, 41, 212)}
+    for k in (0, 1, nz // 2, nz - 1):
+        raw = open(os.path.join(prefix + "_grid_3d", "%d.bmp" % k), "rb").read()
+        assert raw[:2] == b"BM" and int.from_bytes(raw[10:14], "little") == 54 and int.from_bytes(raw[28:30], "little") == 24
+        assert int.from_bytes(raw[18:22], "little") == ny and int.from_bytes(raw[22:26], "little") == nx
+        img = np.frombuffer(raw[54:], np.uint8).reshape(nx, -1)[:, :3 * ny].reshape(nx, ny, 3)[::-1]      # stored bottom-up: x runs down
+        want = np.array([colour[t] for t in nodes.type[:, :, k].ravel()], np.uint8).reshape(nx, ny, 3)
+        assert np.array_equal(img, want), k
+
+
 def test_box_pipe_grid_matches_the_reference_printout(driver, tmp_path):
     """the reference prints `Grid = 64 x 64 x 64` and 115248 NODE_IN points for the shipped example."""
     data, cfgf = (os.path.join(INPUTS, f) for f in CASES["box_pipe"])
