@@ -103,12 +103,17 @@ __device__ __forceinline__ float div_core(float x, float y, float r)
 // The operand tests are running minima (two VALU operations per operand, one register each, no lane masks):
 //   numerators: (bits << 1) - 2, which wraps a zero to the top;  divisors: bits << 1.  Compared once at the end.
 struct DivGuard {
-    unsigned num_min = 0xFFFFFFFFu, den_min = 0xFFFFFFFFu;
+    // numerators >= 2^-100 (or zero); divisors in [2^-30, 2^26): with both, every quotient the core forms is a normal number or zero and
+    // the core's roundings are those of the IEEE division.  One running value each: the minimum of the numerators' exponent fields,
+    // the maximum of (divisor exponent field - low bound) as unsigned -- a divisor below the low bound (or zero) wraps to a huge value
+    // and fails the same test as one above the high bound.
+    static constexpr unsigned DEN_LO = 2u * (97u << 23), DEN_HI = 2u * (153u << 23);      // 2^-30, 2^26
+    unsigned num_min = 0xFFFFFFFFu, den_rng = 0u;
     __device__ __forceinline__ void num(float v) { const unsigned t = (__builtin_bit_cast(unsigned, v) << 1) - 2u; num_min = t < num_min ? t : num_min; asm volatile("" : "+v"(num_min)); }   // opaque: reduce now, do not keep every t alive until the end
-    __device__ __forceinline__ void den(float v) { const unsigned t = __builtin_bit_cast(unsigned, v) << 1; den_min = t < den_min ? t : den_min; asm volatile("" : "+v"(den_min)); }
+    __device__ __forceinline__ void den(float v) { const unsigned t = (__builtin_bit_cast(unsigned, v) << 1) - DEN_LO; den_rng = t > den_rng ? t : den_rng; asm volatile("" : "+v"(den_rng)); }
     __device__ __forceinline__ void num(double) {}
     __device__ __forceinline__ void den(double) {}
-    __device__ __forceinline__ bool plain() const { return num_min >= 2u * (27u << 23) - 2u && den_min >= 2u * (97u << 23); }   // 2^-100, 2^-30
+    __device__ __forceinline__ bool plain() const { return num_min >= 2u * (27u << 23) - 2u && den_rng < DEN_HI - DEN_LO; }
 };
 // x / c.y: FASTM -> core + operand test; otherwise the full division
 template <bool FASTM> __device__ __forceinline__ float divc(float x, const DivC<float> &c, DivGuard &ok)

@@ -416,6 +416,33 @@ def test_division_core_and_its_fallback(built, d, scale, core):
     assert_layers_equal(s, o, capi.LAYER_TEMP, O.L_TEMP, "merged temp")
 
 
+@pytest.mark.parametrize("core", [0, 1])
+@pytest.mark.parametrize("dt", [3e-8, 1e-10])
+@pytest.mark.parametrize("d", [0, 1, 2])
+def test_division_core_large_divisors(built, d, dt, core):
+    """Tiny time steps: the diagonal 3/dt + ... is beyond 2^26 (with a divisor that large and a tiny numerator the quotient
+    is a denormal, where the scaling-free core rounds twice).  Such bundles fail the divisor test of the core and are computed again
+    with full divisions: equal to the oracle value for value, tiny values included."""
+    O = _oracle()
+    dtype = np.float32
+    g = grids.box_with_obstacle(40, 36, 72, h=0.02)
+    params = capi.fluid_params(dtype, *PARAMS)
+    s = capi.Solver(g, params, dtype)
+    s.set_option(capi.OPT_SWEEP_KERNEL, capi.SWEEP_PIPE)
+    s.set_option(capi.OPT_DIV_CORE, core)
+    o = O.Oracle(g, params, dtype)
+    cur, tmp = _scaled_state(g, dtype, 1e-33, 31), _scaled_state(g, dtype, 1e-33, 32)
+    cur[3] = (cur[3].astype(np.float64) * 1e-30).astype(dtype); tmp[3] = (tmp[3].astype(np.float64) * 1e-30).astype(dtype)      # tiny right-hand sides of the T rows too
+    s.upload_layer(capi.LAYER_CUR, cur); s.upload_layer(capi.LAYER_TEMP, tmp)
+    for v in range(4):
+        o.set_field(O.L_CUR, v, cur[v]); o.set_field(O.L_TEMP, v, tmp[v])
+    for _ in range(2):
+        s.sweep(d, dt, capi.LAYER_CUR, capi.LAYER_TEMP, capi.LAYER_NEXT, merge=True)
+        o.sweep(d, dt, O.L_CUR, O.L_TEMP, O.L_NEXT); o.merge(O.L_NEXT, O.L_TEMP)
+    assert_layers_equal(s, o, capi.LAYER_NEXT, O.L_NEXT, "next (dt %g, core %d)" % (dt, core))
+    assert_layers_equal(s, o, capi.LAYER_TEMP, O.L_TEMP, "merged temp")
+
+
 @pytest.mark.parametrize("dims,d", [((160, 12, 70), 0), ((12, 160, 70), 1), ((10, 70, 160), 2)])
 def test_division_core_long_lines(built, dims, d):
     """Same as above for the 32-cells-per-wave instance (lines longer than 128 cells)."""
