@@ -145,6 +145,8 @@ class Hdf5File:
         cdims = struct.unpack("<%dI" % (rank + 1), lay[11:11 + 4 * (rank + 1)])[:rank]
         if any(f not in (1, 2) for f in filters):
             raise Hdf5Error("filters %r: only shuffle and deflate are supported" % (filters,))
+        if any(n == 0 for n in dims + cdims) or int(np.prod(dims, dtype=object)) > 1 << 28 or int(np.prod(cdims, dtype=object)) > 1 << 28:
+            raise Hdf5Error("dataset or chunk too large for this reader (or a corrupt header)")
         out = np.zeros(dims, dtype)
         if btree == UNDEF:
             return out

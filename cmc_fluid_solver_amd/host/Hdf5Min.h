@@ -33,8 +33,9 @@ class Hdf5File {
     }
     bool sig(size_t p, const char *s) const { return p + 4 <= d_.size() && std::memcmp(&d_[p], s, 4) == 0; }
 
-    void walk(size_t p, size_t end, int flags, std::vector<Msg> &out) const
+    void walk(size_t p, size_t end, int flags, std::vector<Msg> &out, int depth = 0) const
     {
+        if (end > d_.size() || depth > 64) throw std::runtime_error("HDF5: object header block past the end of the file");
         while (p + 4 <= end) {
             const int t = d_[p];
             const size_t sz = (size_t)u(p + 1, 2);
@@ -42,8 +43,9 @@ class Hdf5File {
             if (t == 0x10) {                                      // continuation
                 const size_t ca = (size_t)(u(p, 8) + base_), cl = (size_t)u(p + 8, 8);
                 if (!sig(ca, "OCHK")) throw std::runtime_error("HDF5: bad object header continuation");
-                walk(ca + 4, ca + cl - 4, flags, out);
-            } else if (t != 0) out.push_back({t, p, sz});
+                if (cl < 8) throw std::runtime_error("HDF5: bad object header continuation");
+                walk(ca + 4, ca + cl - 4, flags, out, depth + 1);
+            } else if (t != 0) { if (p + sz > end) throw std::runtime_error("HDF5: message past its header block"); out.push_back({t, p, sz}); }
             p += sz;
         }
     }
@@ -156,7 +158,10 @@ public:
         const Info r = info(name);
         const int rank = (int)r.dims.size();
         size_t total = 1;
-        for (uint64_t n : r.dims) total *= (size_t)n;
+        for (uint64_t n : r.dims) {
+            if (n == 0 || n > ((uint64_t)1 << 28) || total > ((size_t)1 << 28) / (size_t)n) throw std::runtime_error("HDF5: dataset too large for this reader (or a corrupt dataspace)");
+            total *= (size_t)n;
+        }
         std::vector<double> out(total, 0.0);
         auto value = [&](const unsigned char *p) { if (r.esize == 4) { float f; std::memcpy(&f, p, 4); return (double)f; } double v; std::memcpy(&v, p, 8); return v; };
         const size_t L = r.layout.pos;
@@ -171,7 +176,11 @@ public:
         const uint64_t btree = u(L + 3, 8);
         std::vector<uint64_t> cd(rank);
         size_t celems = 1;
-        for (int k = 0; k < rank; k++) { cd[k] = u(L + 11 + 4 * k, 4); celems *= (size_t)cd[k]; }
+        for (int k = 0; k < rank; k++) {
+            cd[k] = u(L + 11 + 4 * k, 4);
+            if (cd[k] == 0 || celems > ((size_t)1 << 28) / (size_t)cd[k]) throw std::runtime_error("HDF5: chunk too large for this reader (or a corrupt layout)");
+            celems *= (size_t)cd[k];
+        }
         if (btree == UNDEF) return out;
         std::vector<Chunk> cs;
         chunks(btree, rank, cs);
