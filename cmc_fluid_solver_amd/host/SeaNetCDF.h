@@ -55,7 +55,12 @@ struct SeaNetCDF {
         dimx = (int)std::ceil((float)(mx[0] - mn[0]) / dx) + 1;
         dimy = (int)std::ceil((float)(mx[1] - mn[1]) / dy) + 1;
         dimz = (int)std::ceil((float)(mx[2] - mn[2]) / dz) + 1;
+        for (int a = 0; a < 3; a++) {
+            const double h = a == 0 ? dx : (a == 1 ? dy : dz);
+            if (!(mx[a] >= mn[a]) || !(h > 0) || (double)(mx[a] - mn[a]) / h > 65536.0) throw std::runtime_error("SeaNetCDF: the depth map does not give a grid of a sensible size");
+        }
         if (align) { dimx = AlignBy32(dimx); dimy = AlignBy32(dimy); dimz = AlignBy32(dimz); }
+        if ((double)dimx * dimy * dimz >= 2147483648.0) throw std::runtime_error("SeaNetCDF: grid of more than 2^31 cells");
         g.Resize(dimx, dimy, dimz);
         g.dx = dx; g.dy = dy; g.dz = dz; g.baseT = baseT;
         // Grid3D::Prepare3D_NetCDF

@@ -57,14 +57,16 @@ struct Grid2D {
         size_t i = 0;
         auto next = [&]() -> const std::string & { if (i >= t.size()) throw std::runtime_error("Shape2D file ends early"); return t[i++]; };
         const int num_frames = std::atoi(next().c_str());
-        if (num_frames < 1) throw std::runtime_error("Shape2D file holds no frames");
+        if (num_frames < 1 || (size_t)num_frames > t.size()) throw std::runtime_error("Shape2D file: bad number of frames");
         frames.assign(num_frames, Shape2DFrame());
         for (auto &fr : frames) {                                    // Grid2D.cpp:282-318
             fr.duration = num(next());
             const int nshapes = std::atoi(next().c_str());
+            if (nshapes < 0 || (size_t)nshapes > t.size()) throw std::runtime_error("Shape2D file: bad number of shapes");
             for (int s = 0; s < nshapes; s++) {
                 Shape2DFrame::Shape sh;
                 const int npts = std::atoi(next().c_str());
+                if (npts < 0 || (size_t)npts > t.size()) throw std::runtime_error("Shape2D file: bad number of points");
                 for (int p = 0; p < npts; p++) {
                     const float x = num(next()), y = num(next());
                     sh.px.push_back(x * GRID_SCALE_FACTOR); sh.py.push_back(y * GRID_SCALE_FACTOR);
@@ -108,10 +110,14 @@ struct Grid2D {
         pminx = pminx - wx * BBOX_PADDING; pminy = pminy - wy * BBOX_PADDING;
         pmaxx = pmaxx + wx * BBOX_PADDING; pmaxy = pmaxy + wy * BBOX_PADDING;
         bbox[0] = pminx; bbox[1] = pminy; bbox[2] = pmaxx; bbox[3] = pmaxy;
+        // (a corrupt coordinate or a tiny grid step: refuse before anything of that size is allocated or rasterised)
+        if (!(pmaxx >= pminx) || !(pmaxy >= pminy) || !(dx > 0) || !(dy > 0) || (double)(pmaxx - pminx) / dx > 65536.0 || (double)(pmaxy - pminy) / dy > 65536.0)
+            throw std::runtime_error("Shape2D: the shapes do not give a grid of a sensible size (more than 65536 cells along an axis, or no points)");
         // Grid2D::Init (Grid2D.cpp:212-246)
         dimx = (int)std::ceil((double)(float)(pmaxx - pminx) / dx) + 1;
         dimy = (int)std::ceil((double)(float)(pmaxy - pminy) / dy) + 1;
         if (align) { dimx = AlignBy32(dimx); dimy = AlignBy32(dimy); }
+        if ((double)dimx * dimy > 268435456.0) throw std::runtime_error("Shape2D: more than 2^28 cells in the plane");
         const float fdx = (float)dx, fdy = (float)dy;
         for (auto &fr : frames)
             for (auto &sh : fr.shapes) {
@@ -221,8 +227,10 @@ void LoadShape2D(Grid3D<FTYPE> &g, Grid2D &g2, const std::string &path, double d
 {
     g2.Load(path, dx, dy, baseT, align);
     const int dimx = g2.dimx, dimy = g2.dimy;
+    if (!(dz > 0) || !(depth >= 0) || depth / dz > 65536.0) throw std::runtime_error("Shape2D: depth / grid_dz gives more than 65536 cells");
     const int active_dimz = (int)std::ceil(depth / dz) + 1;                 // Grid3D.cpp:503-505
     const int dimz = align ? AlignBy32(active_dimz) : active_dimz;
+    if ((double)dimx * dimy * dimz >= 2147483648.0) throw std::runtime_error("Shape2D: grid of more than 2^31 cells");
     g.Resize(dimx, dimy, dimz);
     g.dx = dx; g.dy = dy; g.dz = dz; g.baseT = baseT;
     // memset(nodes, 0): type NODE_IN, bc NOSLIP, v = 0, T = 0   (Grid3D.cpp:612)

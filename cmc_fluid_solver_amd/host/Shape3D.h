@@ -54,16 +54,18 @@ struct Shape3D {
         size_t i = 0;
         auto next = [&]() -> const std::string & { if (i >= t.size()) throw std::runtime_error("Shape3D file ends early"); return t[i++]; };
         const int nf = std::atoi(next().c_str());
-        if (nf < 1) throw std::runtime_error("Shape3D file holds no frames");
+        if (nf < 1 || (size_t)nf > t.size()) throw std::runtime_error("Shape3D file: bad number of frames");
         frames.assign(nf, Shape3DFrame());
         for (auto &fr : frames) {
             const int nv = std::atoi(next().c_str());
+            if (nv < 0 || (size_t)nv > t.size()) throw std::runtime_error("Shape3D file: bad number of vertices");
             for (int k = 0; k < nv; k++) {
                 const float px = num(next()), py = num(next()), pz = num(next());
                 fr.x.push_back(px * GRID_SCALE_FACTOR); fr.y.push_back(py * GRID_SCALE_FACTOR); fr.z.push_back(pz * GRID_SCALE_FACTOR);
                 fr.vx.push_back(num(next())); fr.vy.push_back(num(next())); fr.vz.push_back(num(next()));
             }
             const int nt = std::atoi(next().c_str());
+            if (nt < 0 || (size_t)nt > t.size()) throw std::runtime_error("Shape3D file: bad number of triangles");
             for (int k = 0; k < 3 * nt; k++) {
                 const int v = std::atoi(next().c_str());
                 if (v < 0 || v >= nv) throw std::runtime_error("Shape3D: triangle index outside the vertex list");
@@ -86,11 +88,17 @@ struct Shape3D {
             mn[a] = mn[a] - pad; mx[a] = mx[a] + pad;
             bbox[a] = mn[a]; bbox[3 + a] = mx[a];
         }
+        for (int a = 0; a < 3; a++) {
+            const double h = a == 0 ? dx : (a == 1 ? dy : dz);
+            if (!(mx[a] >= mn[a]) || !(h > 0) || (double)(mx[a] - mn[a]) / h > 65536.0)
+                throw std::runtime_error("Shape3D: the mesh does not give a grid of a sensible size (more than 65536 cells along an axis, or no vertices)");
+        }
         // Grid3D::Init
         dimx = (int)std::ceil((float)(mx[0] - mn[0]) / dx) + 1;
         dimy = (int)std::ceil((float)(mx[1] - mn[1]) / dy) + 1;
         dimz = (int)std::ceil((float)(mx[2] - mn[2]) / dz) + 1;
         if (align) { dimx = AlignBy32(dimx); dimy = AlignBy32(dimy); dimz = AlignBy32(dimz); }
+        if ((double)dimx * dimy * dimz >= 2147483648.0) throw std::runtime_error("Shape3D: grid of more than 2^31 cells");
         // physical -> grid coordinates (Grid3D.cpp:420-428)
         for (auto &fr : frames)
             for (size_t k = 0; k < fr.x.size(); k++) {
