@@ -101,25 +101,26 @@ def main():
             sv.comm_init(bytes(uid.cpu().numpy().tobytes()), rank, world)
         return sv, xa, xb
 
-    # multi-GPU self-check (untimed): a 64^3 box stepped on N slabs against the single-GPU fields (the X sweep of a slab runs
+    # multi-GPU self-check (untimed): a 128^3 box stepped on N slabs against the single-GPU fields (the X sweep of a slab runs
     # the exact cross-slab halves, the single GPU the partition kernel: equal to rounding, not bit for bit)
     mgpu_check = None
     if world > 1:
-        gs = grids.box(64, h=1.0 / 63)
+        NC = 128
+        gs = grids.box(NC, h=1.0 / (NC - 1))
         sv, xa, xb = make_solver(gs)
         errs = []
         for i in range(2):
             sv.UpdateBoundaries()
             errs.append(sv.TimeStep(dt, NUM_GLOBAL, NUM_LOCAL, True))
-        mine = np.stack(sv.download_layer(capi.LAYER_CUR))                    # [4, nx, 64, 64]
-        pad = np.zeros((4, (64 + world - 1) // world + 1, 64, 64), dtype=dtype)
+        mine = np.stack(sv.download_layer(capi.LAYER_CUR))                    # [4, nx, NC, NC]
+        pad = np.zeros((4, (NC + world - 1) // world + 1, NC, NC), dtype=dtype)
         pad[:, :xb - xa] = mine
         tl = [torch.empty(pad.shape, dtype=torch.float32 if dtype == np.float32 else torch.float64, device="cuda")
               for _ in range(world)]
         dist.all_gather(tl, torch.from_numpy(pad).cuda())
         sv.close()
         if rank == 0:
-            full = np.concatenate([tl[r].cpu().numpy()[:, :slab_range(64, r, world)[1] - slab_range(64, r, world)[0]]
+            full = np.concatenate([tl[r].cpu().numpy()[:, :slab_range(NC, r, world)[1] - slab_range(NC, r, world)[0]]
                                    for r in range(world)], axis=1)
             s1 = capi.Solver(gs, params, dtype, device=local_rank)
             errs1 = []
@@ -129,7 +130,7 @@ def main():
             ref = np.stack(s1.download_layer(capi.LAYER_CUR))
             s1.close()
             rl2 = float(np.linalg.norm(full.astype(np.float64) - ref) / np.linalg.norm(ref.astype(np.float64)))
-            mgpu_check = {"grid": [64, 64, 64], "steps": 2, "fields_bit_identical_to_single_gpu": bool(np.array_equal(full, ref)),
+            mgpu_check = {"grid": [NC, NC, NC], "steps": 2, "fields_bit_identical_to_single_gpu": bool(np.array_equal(full, ref)),
                           "rel_l2_vs_single_gpu": rl2, "fields_match_single_gpu": bool(rl2 <= 2e-6),
                           "max_abs_diff": float(np.abs(full - ref).max()),
                           "div_error_rel_diff": float(abs(errs[-1] - errs1[-1]) / abs(errs1[-1]))}

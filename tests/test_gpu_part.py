@@ -467,11 +467,11 @@ def test_slab_interface_words_from_the_partition_kernel(built, dimx, nranks, onc
     assert vec_rel(full, ref_cur) <= TOL_STEPS and rel(full[3], ref_cur[3]) <= TOL_STEPS
 
 
-@pytest.mark.parametrize("nslabs", [4, 8])
-def test_slabs_default_is_the_reduced_interface_solve(built, nslabs):
+@pytest.mark.parametrize("n,nslabs", [(64, 4), (64, 8), (128, 2), (128, 8)])
+def test_slabs_default_is_the_reduced_interface_solve(built, n, nslabs):
     """FS3D_SWEEP_AUTO on slabs: partition kernels for Y and Z, the reduced-interface X solve; against one context (AUTO).
-    (8 slabs of the 64^3 box = the self-check bench.py --gpus 8 runs before it times anything.)"""
-    g = grids.box(64, h=1.0 / 63)
+    (N slabs of the 128^3 box = the self-check bench.py --gpus N runs before it times anything.)"""
+    g = grids.box(n, h=1.0 / (n - 1))
     params = capi.fluid_params(np.float32, *PARAMS)
     s = capi.Solver(g, params, np.float32)
     for i in range(2):
