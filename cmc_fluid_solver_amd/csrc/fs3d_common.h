@@ -110,7 +110,9 @@ struct fs3d_ctx {
     int ran_segmented[3] = {0, 0, 0};
     int opt_fuse = 1;
     // timing
-    bool timing = false;
+    bool timing = false;           // events around the launches being enqueued now
+    int timing_period = 0;         // fs3d_enable_timing(on): 0 off, 1 every time step, N every N-th time step (sampling)
+    long timing_steps = 0;
     std::vector<hipEvent_t> ev;
     size_t ev_used = 0;
     std::vector<int> ev_class;

@@ -321,6 +321,7 @@ extern "C" fs3d_status fs3d_enable_timing(fs3d_ctx *c, int on)
 {
     if (!c) return FS3D_ERR_INVALID;
     c->timing = on != 0;
+    c->timing_period = on > 0 ? on : 0; c->timing_steps = 0;
     for (int k = 0; k < 8; k++) { c->t_ms[k] = 0; c->t_n[k] = 0; }
     return FS3D_OK;
 }
@@ -946,7 +947,7 @@ extern "C" fs3d_status fs3d_sweep(fs3d_ctx *c, int dir, double dt, int l_cur, in
         }
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->timing) rec_collect(c);
+    if (c->ev_used) rec_collect(c);
     return check_device_errors(c);
 }
 
@@ -1031,6 +1032,7 @@ extern "C" fs3d_status fs3d_time_step(fs3d_ctx *c, double dt, int G, int L, int 
     if (!c->have_nodes || !c->have_params) return fail(c, FS3D_ERR_INVALID, "fs3d_time_step: upload nodes and set params first");
     if (G < 0 || L < 0 || !(dt > 0)) return fail(c, FS3D_ERR_INVALID, "fs3d_time_step: bad dt / iteration counts");
     HIPCHK(c, hipSetDevice(c->device));
+    if (c->timing_period > 1) c->timing = (c->timing_steps++ % c->timing_period) == 0;      // sampled timing: every N-th time step carries the events
     fs3d_status st = c->prec == FS3D_F32 ? time_step_enqueue<float>(c, dt, G, L, compute_error != 0)
                                          : time_step_enqueue<double>(c, dt, G, L, compute_error != 0);
     if (st) return st;
@@ -1041,7 +1043,7 @@ extern "C" fs3d_status fs3d_time_step(fs3d_ctx *c, double dt, int G, int L, int 
     } else {
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
-    if (c->timing) rec_collect(c);
+    if (c->ev_used) rec_collect(c);
     if ((st = check_device_errors(c))) return st;
     if (err_out) *err_out = c->diffError;
     if (c->diffError > 0.01) {                                               // :371-374 (ERR_THRESHOLD, AdiSolver3D.h:32)
@@ -1058,6 +1060,7 @@ extern "C" fs3d_status fs3d_time_step_async(fs3d_ctx *c, double dt, int G, int L
     if (!c->have_nodes || !c->have_params) return fail(c, FS3D_ERR_INVALID, "fs3d_time_step_async: upload nodes and set params first");
     if (G < 0 || L < 0 || !(dt > 0)) return fail(c, FS3D_ERR_INVALID, "fs3d_time_step_async: bad dt / iteration counts");
     HIPCHK(c, hipSetDevice(c->device));
+    if (c->timing_period > 1) c->timing = (c->timing_steps++ % c->timing_period) == 0;
     fs3d_status st = c->prec == FS3D_F32 ? update_boundaries_impl<float>(c) : update_boundaries_impl<double>(c);
     if (st) return st;
     st = c->prec == FS3D_F32 ? time_step_enqueue<float>(c, dt, G, L, false) : time_step_enqueue<double>(c, dt, G, L, false);
@@ -1079,7 +1082,7 @@ extern "C" fs3d_status fs3d_synchronize(fs3d_ctx *c)
     if (!c) return FS3D_ERR_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->timing) rec_collect(c);
+    if (c->ev_used) rec_collect(c);
     return check_device_errors(c);
 }
 

@@ -204,7 +204,8 @@ fs3d_status fs3d_last_step_timing(fs3d_ctx *ctx, float ms[4], int n[4]);
  * static strings.  The driver prints them as the reference's PrintTimings table. */
 #define FS3D_N_EVENTS 9
 fs3d_status fs3d_profiler_events(fs3d_ctx *ctx, const char *names[FS3D_N_EVENTS], float ms[FS3D_N_EVENTS], int n[FS3D_N_EVENTS]);
-/* enable/disable per-class event timing (adds 2 events per launch; default off) */
+/* per-class event timing: 0 off (default), 1 two events around every launch, N > 1 the same on every N-th time step only
+ * (a sample: the events themselves cost a few microseconds per launch) */
 fs3d_status fs3d_enable_timing(fs3d_ctx *ctx, int on);
 
 /* One pipelined sweep (merge fused, result discarded into the spare temp buffer) with

@@ -5,7 +5,10 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cmc_fluid_solver_amd import capi, grids
 
-for dims in ((256, 256, 256), (256, 256, 256), (256, 248, 256), (248, 256, 256), (256, 252, 256), (252, 256, 256)):
+DIMS = ((256, 256, 256), (256, 256, 256), (256, 248, 256), (248, 256, 256), (256, 252, 256), (252, 256, 256))
+if os.environ.get('STRIDE_SMALL_PLANES'):
+    DIMS = ((256, 256, 256), (256, 256, 256), (256, 128, 256), (256, 256, 128), (256, 128, 128), (256, 64, 256), (256, 512, 128))
+for dims in DIMS:
     g = grids.box(*dims, h=1.0 / 255)
     s = capi.Solver(g, capi.fluid_params(np.float32, 200.0, 0.72, 1.4), np.float32)
     for i in range(2):
