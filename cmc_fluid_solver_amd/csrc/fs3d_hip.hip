@@ -76,6 +76,21 @@ __global__ void __launch_bounds__(256) k_impose_list(const int *__restrict__ idx
     if (t < n) { int i = idx[t]; d0[i] = v0[t]; d1[i] = v1[t]; d2[i] = v2[t]; d3[i] = v3[t]; }
 }
 
+// both of the above in one pass, for UpdateBoundaries directly followed by TimeStep (fs3d_time_step_async): the node values of the
+// listed cells into cur AND next (next[i] = cur[i] = v)
+template <typename R>
+__global__ void __launch_bounds__(256) k_impose_list2(const int *__restrict__ idx, int n,
+                                                       const R *v0, const R *v1, const R *v2, const R *v3,
+                                                       R *d0, R *d1, R *d2, R *d3, R *e0, R *e1, R *e2, R *e3)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) {
+        int i = idx[t];
+        const R a = v0[t], b = v1[t], c = v2[t], d = v3[t];
+        d0[i] = a; d1[i] = b; d2[i] = c; d3[i] = d; e0[i] = a; e1[i] = b; e2[i] = c; e3[i] = d;
+    }
+}
+
 // TimeLayer3D::Clear(grid, NODE_OUT, MISSING_VALUE x4) (TimeLayer3D.h:974-999; `clear`, TimeLayer3D.cu:98-116)
 template <typename R>
 __global__ void __launch_bounds__(256) k_clear_type(const uint16_t *__restrict__ code, long long n, int type, R val,
@@ -855,11 +870,17 @@ static fs3d_status merge_buffers(fs3d_ctx *c, int b_src, int b_dest)
 }
 
 template <typename R>
-static fs3d_status update_boundaries_impl(fs3d_ctx *c)
+static fs3d_status update_boundaries_impl(fs3d_ctx *c, bool also_next = false)
 {
     if (!c->n_bnd) return FS3D_OK;
     const int b = c->slot[FS3D_LAYER_CUR];
     rec_begin(c, 6);
+    if (also_next) {
+        const int bn = c->slot[FS3D_LAYER_NEXT];
+        hipLaunchKernelGGL((k_impose_list2<R>), dim3((c->n_bnd + 255) / 256), dim3(256), 0, c->stream, c->bnd_idx, c->n_bnd,
+                           (const R *)c->bnd_val[0], (const R *)c->bnd_val[1], (const R *)c->bnd_val[2], (const R *)c->bnd_val[3],
+                           fld<R>(c, b, 0), fld<R>(c, b, 1), fld<R>(c, b, 2), fld<R>(c, b, 3), fld<R>(c, bn, 0), fld<R>(c, bn, 1), fld<R>(c, bn, 2), fld<R>(c, bn, 3));
+    } else
     hipLaunchKernelGGL((k_impose_list<R>), dim3((c->n_bnd + 255) / 256), dim3(256), 0, c->stream, c->bnd_idx, c->n_bnd,
                        (const R *)c->bnd_val[0], (const R *)c->bnd_val[1], (const R *)c->bnd_val[2], (const R *)c->bnd_val[3],
                        fld<R>(c, b, 0), fld<R>(c, b, 1), fld<R>(c, b, 2), fld<R>(c, b, 3));
@@ -966,12 +987,12 @@ extern "C" fs3d_status fs3d_merge(fs3d_ctx *c, int l_src, int l_dest)
 
 // AdiSolver3D::TimeStep, AdiSolver3D.cpp:306-391, enqueued on the context's stream.
 template <typename R>
-static fs3d_status time_step_enqueue(fs3d_ctx *c, double dt, int G, int L, bool compute_error)
+static fs3d_status time_step_enqueue(fs3d_ctx *c, double dt, int G, int L, bool compute_error, bool bnd_copied = false)
 {
     const int bCur = c->slot[FS3D_LAYER_CUR], bNext = c->slot[FS3D_LAYER_NEXT], bHalf = c->slot[FS3D_LAYER_HALF];
     fs3d_status st;
     // :310-311  cur -> next on NODE_BOUND and NODE_VALVE
-    if (c->n_bnd) {
+    if (c->n_bnd && !bnd_copied) {
         rec_begin(c, 3);
         hipLaunchKernelGGL((k_copy_list<R>), dim3((c->n_bnd + 255) / 256), dim3(256), 0, c->stream, c->bnd_idx, c->n_bnd,
                            (const R *)fld<R>(c, bCur, 0), (const R *)fld<R>(c, bCur, 1), (const R *)fld<R>(c, bCur, 2), (const R *)fld<R>(c, bCur, 3),
@@ -1061,9 +1082,10 @@ extern "C" fs3d_status fs3d_time_step_async(fs3d_ctx *c, double dt, int G, int L
     if (G < 0 || L < 0 || !(dt > 0)) return fail(c, FS3D_ERR_INVALID, "fs3d_time_step_async: bad dt / iteration counts");
     HIPCHK(c, hipSetDevice(c->device));
     if (c->timing_period > 1) c->timing = (c->timing_steps++ % c->timing_period) == 0;
-    fs3d_status st = c->prec == FS3D_F32 ? update_boundaries_impl<float>(c) : update_boundaries_impl<double>(c);
+    // UpdateBoundaries and the cur -> next copy of the boundary cells that opens TimeStep: one pass over the list
+    fs3d_status st = c->prec == FS3D_F32 ? update_boundaries_impl<float>(c, true) : update_boundaries_impl<double>(c, true);
     if (st) return st;
-    st = c->prec == FS3D_F32 ? time_step_enqueue<float>(c, dt, G, L, false) : time_step_enqueue<double>(c, dt, G, L, false);
+    st = c->prec == FS3D_F32 ? time_step_enqueue<float>(c, dt, G, L, false, true) : time_step_enqueue<double>(c, dt, G, L, false, true);
     if (st) return st;
     std::swap(c->slot[FS3D_LAYER_CUR], c->slot[FS3D_LAYER_NEXT]);
     return FS3D_OK;

@@ -581,3 +581,23 @@ def test_slab_kernels_of_wide_grids(built, nranks):
     grp.close()
     full = [np.concatenate([r[v] for r in res], axis=0) for v in range(4)]
     assert vec_rel(full, ref_cur) <= TOL_STEPS and rel(full[3], ref_cur[3]) <= TOL_STEPS
+
+
+@pytest.mark.parametrize("kernel", [capi.SWEEP_AUTO, capi.SWEEP_EXACT])
+def test_async_step_equals_update_boundaries_plus_time_step(built, kernel):
+    """fs3d_time_step_async = UpdateBoundaries + TimeStep enqueued without a host synchronisation (what bench.py times; it imposes
+    the boundary values on cur and next in one pass over the list): the same fields, bit for bit, as the two calls."""
+    g = grids.box_with_obstacle(70, 40, 36, h=0.02)
+    params = capi.fluid_params(np.float32, *PARAMS)
+    a = capi.Solver(g, params, np.float32); a.set_option(capi.OPT_SWEEP_KERNEL, kernel)
+    b = capi.Solver(g, params, np.float32); b.set_option(capi.OPT_SWEEP_KERNEL, kernel)
+    for i in range(4):
+        a.UpdateBoundaries(); a.TimeStep(DT, 2, 2, i == 2)
+        b.time_step_async(DT, 2, 2)
+    b.synchronize()
+    for layer in (capi.LAYER_CUR, capi.LAYER_NEXT):
+        for x, y in zip(a.download_layer(layer), b.download_layer(layer)):
+            assert np.array_equal(x, y)
+    ea, _ = a.eval_div_error(capi.LAYER_CUR); eb, _ = b.eval_div_error(capi.LAYER_CUR)
+    assert ea == eb
+    a.close(); b.close()
