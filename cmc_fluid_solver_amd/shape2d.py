@@ -178,10 +178,10 @@ class Grid2D:
         self.velx[inout], self.vely[inout], self.T[inout] = 0, 0, F(self.startT)
 
 
-def load_shape2d(path_or_text, dx, dy, dz, depth, depth_var=0.0, baseT=1.0, align=True, is_text=False):
-    """Grid3D(dx,dy,dz,depth,depth_var,baseT) + LoadFromFile + Prepare2D(0) -> (Nodes, Grid2D)."""
+def load_shape2d(path_or_text, dx, dy, dz, depth, depth_var=0.0, baseT=1.0, align=True, is_text=False, time=0.0):
+    """Grid3D(dx,dy,dz,depth,depth_var,baseT) + LoadFromFile + Prepare2D(time) -> (Nodes, Grid2D)."""
     text = path_or_text if is_text else open(path_or_text, "r").read()
-    g2 = Grid2D(parse_shape2d(text), dx, dy, baseT, align)
+    g2 = Grid2D(parse_shape2d(text), dx, dy, baseT, align, time)
     dimx, dimy = g2.dimx, g2.dimy
     active_dimz = int(math.ceil(depth / dz)) + 1                     # Grid3D.cpp:503-505
     dimz = align_by_32(active_dimz) if align else active_dimz

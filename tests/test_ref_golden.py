@@ -1,0 +1,112 @@
+"""The CPU oracle and the Shape2D loader held to OUTPUTS OF THE REFERENCE ITSELF (tests/golden/ref_*.npz, made by
+tests/golden/make_ref_golden.py from the reference's own translation units compiled where they lie -- `make -C oracle ref_full`).
+
+Bar: bit for bit.  Every field of every dumped step (sha256 of the raw array, and the arrays themselves where the fixture
+holds them in full), every printed `err`, the EvalDivError value in full double precision, and every result layer GetLayer
+hands to the NetCDF writer.  fp32 = the reference as shipped; fp64 = its FTYPE-switched build.
+"""
+import numpy as np
+import pytest
+
+import refgolden as RG
+from cmc_fluid_solver_amd import grids, shape2d
+
+SMALL = [c for c in RG.ALL if c[0] not in ("box256", "non_uniform256")]
+BIG = [c for c in RG.ALL if c[0] in ("box256", "non_uniform256")]
+
+
+def _hold(fx, eng, max_steps=None):
+    m = fx.meta
+    seen = {"steps": [], "layers": []}
+
+    def on_step(step, e):
+        f = e.fields()
+        for v, a in zip("UVWT", f):
+            assert a.dtype == fx.dtype
+            want = fx.field(v, step)
+            if want is not None:
+                assert np.array_equal(a, want), "%s step %d: %g" % (v, step, np.abs(a - want).max())
+            assert RG.sha(a) == m["step_sha"][str(step)][v], "%s after step %d differs from the reference" % (v, step)
+            smp = fx.sample(v, step)
+            if smp is not None:
+                s = m["stride"]
+                assert np.array_equal(a[::s, ::s, ::s], smp)
+        assert e.div_error() == m["step_err"][str(step)]          # same serial summation as TimeLayer3D.h:595-641
+        seen["steps"].append(step)
+
+    def on_layer(step, V, T):
+        want = m["layer_sha"][str(step)]
+        assert RG.sha(V) == want["outV"] and RG.sha(T) == want["outT"], "result layer at step %d" % step
+        if "outV_step%d" % step in fx.z:
+            assert np.array_equal(V, fx.z["outV_step%d" % step]) and np.array_equal(T, fx.z["outT_step%d" % step])
+        seen["layers"].append(step)
+
+    errs = RG.replay(fx, eng, on_step, on_layer, max_steps)
+    n = len(errs)
+    assert ["%.8f" % e for e in errs] == ["%.8f" % e for e in m["err_trace"][:n]]      # what the reference prints every step
+    if max_steps is None:
+        assert seen["steps"] == sorted(set(m["hashed_steps"]) | set(m["full_steps"])) and seen["layers"] == m["layer_steps"]
+    return seen
+
+
+@pytest.mark.parametrize("name,prec", SMALL, ids=["%s-%s" % c for c in SMALL])
+def test_oracle_equals_the_reference(built, name, prec):
+    fx = RG.Fixture(name, prec)
+    eng = RG.OracleEngine(fx)
+    try:
+        _hold(fx, eng)
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("name,prec", BIG, ids=["%s-%s" % c for c in BIG])
+def test_oracle_equals_the_reference_at_256_cubed(built, name, prec):
+    """BASELINE configs[2] and configs[4] at full size: the first two steps."""
+    fx = RG.Fixture(name, prec)
+    eng = RG.OracleEngine(fx)
+    try:
+        _hold(fx, eng, max_steps=2)
+    finally:
+        eng.close()
+
+
+F32 = [c for c in RG.ALL if c[1] == "f32"]
+
+
+@pytest.mark.parametrize("name,prec", F32, ids=[c[0] for c in F32])
+def test_shape2d_loader_equals_the_reference(name, prec):
+    """Grid2D/Grid3D construction from the input files: dims, dt, FluidParams and every node (type, both BC kinds, boundary
+    values) equal what the reference's own Grid3D holds after LoadFromFile + Prepare(0)."""
+    fx = RG.Fixture(name, prec)
+    m = fx.meta
+    nodes, cfg, dt = fx.loader()
+    want = fx.nodes()
+    assert nodes.shape == fx.dims and (nodes.dx, nodes.dy, nodes.dz) == (m["dx"], m["dy"], m["dz"])
+    assert dt == m["dt"] and cfg.grid2d.num_frames == m["frames"] and cfg.grid2d.cycle_length() == m["cycle_length"]
+    assert nodes.count(grids.NODE_IN) == m["node_in"]
+    assert np.array_equal(nodes.type, want.type)
+    assert np.array_equal(nodes.bc_vel, want.bc_vel) and np.array_equal(nodes.bc_temp, want.bc_temp)
+    for k in ("vx", "vy", "vz", "T"):
+        assert np.array_equal(np.asarray(getattr(nodes, k), np.float32), np.asarray(getattr(want, k), np.float32)), k
+    from cmc_fluid_solver_amd import capi
+    p = capi.fluid_params(np.float32, cfg.Re, cfg.Pr, cfg.lam)
+    assert tuple(float(x) for x in p) == tuple(m["params"])
+    # the node arrays hash to what the reference's hold (vel interleaved as Vec3D)
+    vel = np.stack([np.asarray(getattr(nodes, k), np.float32) for k in ("vx", "vy", "vz")], axis=-1)
+    assert RG.sha(vel) == m["nodes_sha"]["vel"] and RG.sha(np.asarray(nodes.T, np.float32)) == m["nodes_sha"]["T"]
+    assert RG.sha(nodes.type) == m["nodes_sha"]["type"]
+
+
+def test_multi_frame_geometry_equals_the_reference():
+    """Grid3D::Prepare_CPU(t) of the multi-frame heart_us input at times inside and between frames: the interpolated sub-frame's
+    node types and wall velocities (Grid2D.cpp:375-478)."""
+    fx = RG.Fixture("heart_us", "f32")
+    m = fx.meta
+    cfg = fx.cfg()
+    assert m["frames"] == 10 and len(m["grid_times"]) == 6
+    for i, t in enumerate(m["grid_times"]):
+        nodes, g2 = shape2d.load_shape2d(fx.data_path, cfg.dx, cfg.dy, cfg.dz, cfg.depth, cfg.depth_var, cfg.baseT, m["align"], time=t)
+        want_t = fx.z["grid%d_type" % i]
+        assert np.array_equal(nodes.type, want_t), "node types at t = %g" % t
+        vel = np.stack([np.asarray(getattr(nodes, k), np.float32) for k in ("vx", "vy", "vz")], axis=-1)
+        assert np.array_equal(vel[want_t >= 2], fx.z["grid%d_bnd_vel" % i]), "wall velocities at t = %g" % t
