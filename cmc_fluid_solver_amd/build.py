@@ -56,7 +56,7 @@ def build_variant(name, extra_flags, source="kernels_part.hip"):
     build()
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     obj = os.path.join(CSRC, source.replace(".hip", "_var_%s.o" % name))
-    subprocess.check_call([hipcc] + FLAGS_BY_SOURCE.get(source, FLAGS) + list(extra_flags) + ["-c", os.path.join(CSRC, source), "-o", obj])
+    subprocess.check_call([hipcc] + FLAGS_BY_SOURCE.get(source, FLAGS) + ["-DFS3D_EXPERIMENTS"] + list(extra_flags) + ["-c", os.path.join(CSRC, source), "-o", obj])
     objs = [obj if s == source else os.path.join(CSRC, s.replace(".hip", ".o")) for s in SOURCES]
     lib = os.path.join(HERE, "libfs3d_hip_%s.so" % name)
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"])

@@ -68,6 +68,8 @@ struct SweepParams {
     int store_next;             // pipe kernel, fused time step: 0 when a later local iteration overwrites `next` unread (only the merge uses x)
 };
 
+#define FS3D_XREDUCE_MAX_RANKS 64      // k_xreduce (kernels_line.hip) holds the R x R slab system of a line in per-thread arrays of this size
+
 struct fs3d_ctx {
     int device = 0;
     fs3d_precision prec = FS3D_F32;
@@ -99,6 +101,7 @@ struct fs3d_ctx {
     double *red_host = nullptr;    // pinned
     int red_blocks = 0;
     double diffError = 0.0;
+    int test_drop = 0;             // fault-injection hook of tests/test_gpu_failures.py: env FS3D_TEST_DROP_HANDOFF, read ONCE at fs3d_create
     hipStream_t stream = nullptr;
     hipStream_t comm_stream = nullptr;     // multi-GPU: halo planes travel here, beside the interior planes' sweep on `stream`
     hipStream_t xstream = nullptr;         // the stream the transport works on right now (stream or comm_stream)

@@ -236,6 +236,7 @@ extern "C" fs3d_status fs3d_create(fs3d_ctx **out, int device, fs3d_precision pr
     c->gdx = dx; c->gdy = dy; c->gdz = dz;
     c->esize = prec == FS3D_F32 ? 4 : 8;
     c->plane = (long long)dimy * dimz; c->ncell = c->plane * dimx;
+    if (const char *e = getenv("FS3D_TEST_DROP_HANDOFF")) c->test_drop = atoi(e) ? 1 : 0;
     if (const char *e = getenv("FS3D_DEFAULT_KERNEL")) {       // initial FS3D_OPT_SWEEP_KERNEL of new contexts (tests: 4 = bit-exact kernels only)
         const int v = atoi(e);
         if (v >= FS3D_SWEEP_AUTO && v <= FS3D_SWEEP_EXACT) c->opt_kernel = v;
@@ -597,7 +598,7 @@ static void fill_params(fs3d_ctx *c, SweepParams<R> &p, int dir, double dt_, int
     p.stamps = nullptr;
     p.errw = c->errw_dev;
     p.o_begin = 0; p.o_count = 0;
-    { const char *e = getenv("FS3D_TEST_DROP_HANDOFF"); p.test_drop = (e && atoi(e)) ? 1 : 0; }
+    p.test_drop = c->test_drop;
     p.xiface_pass = 0;
     p.carry_in = nullptr; p.carry_out = nullptr; p.xcarry_in = nullptr; p.xcarry_out = nullptr; p.bundle0 = 0;
     p.seg_begin = 0; p.seg_len = 0; p.carry_pitch = c->plane; p.seg_index = 0; p.scr_bundles = 0;
@@ -616,6 +617,21 @@ static fs3d_status ensure_scratch(fs3d_ctx *c)
     return FS3D_OK;
 }
 
+// carry buffers of the cross-slab X sweeps ([value][line]: 6 forward, 4 backward words per line); failure is a status, not an
+// early return past the callers' abort guard
+static fs3d_status ensure_carries(fs3d_ctx *c)
+{
+    if (c->carry[0] && c->carry[1] && c->carry[2] && c->carry[3]) return FS3D_OK;
+    const size_t pl = (size_t)c->plane;
+    const size_t words[4] = {6, 6, 4, 4};
+    for (int k = 0; k < 4; k++)
+        if (!c->carry[k] && hipMalloc(&c->carry[k], words[k] * pl * c->esize) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(c, FS3D_ERR_HIP, "cross-slab X sweep: hipMalloc of the carry buffers failed");
+        }
+    return FS3D_OK;
+}
+
 // Cross-slab X sweep (nranks > 1): forward over the slabs 0 -> R-1, backward R-1 -> 0, carries over RCCL.
 // The lines of the plane are cut into `xblocks` blocks that travel through the ranks as a pipeline (rank r
 // works on block b while rank r+1 works on block b-1) -- the reference's `blocking` idea (AdiSolver3D.cu:642-881).
@@ -623,14 +639,14 @@ static fs3d_status ensure_scratch(fs3d_ctx *c)
 template <typename R>
 static fs3d_status xsweep_multi(fs3d_ctx *c, SweepParams<R> &p)
 {
-    fs3d_status st = ensure_scratch(c);
-    if (st) return st;
+    // a rank that fails anywhere in here -- allocations included -- must not leave its neighbours blocked in their receives: it
+    // aborts the group (fs3d_comm_abort), the peers' pending and later exchanges return FS3D_ERR_COMM
+    fs3d_status st = FS3D_OK;
+    struct AbortOnError { fs3d_ctx *c; fs3d_status *st; ~AbortOnError() { if (*st != FS3D_OK) fs3d_comm_abort(c); } } guard{c, &st};
+    if ((st = ensure_scratch(c))) return st;
     p.scr_ = (R *)c->scr;
     const size_t pl = (size_t)c->plane;
-    if (!c->carry[0]) {
-        HIPCHK(c, hipMalloc(&c->carry[0], 6 * pl * c->esize)); HIPCHK(c, hipMalloc(&c->carry[1], 6 * pl * c->esize));
-        HIPCHK(c, hipMalloc(&c->carry[2], 4 * pl * c->esize)); HIPCHK(c, hipMalloc(&c->carry[3], 4 * pl * c->esize));
-    }
+    if ((st = ensure_carries(c))) return st;
     const bool first = c->rank == 0, last = c->rank == c->nranks - 1;
     const int nb = c->xblocks < 1 ? 1 : c->xblocks;
     // per-slab halves: the pipe kernel (rows on chip, 64 lines per bundle) where the slab allows it, else thread-per-line
@@ -643,9 +659,6 @@ static fs3d_status xsweep_multi(fs3d_ctx *c, SweepParams<R> &p)
     };
     p.carry_in = first ? nullptr : (const R *)c->carry[0]; p.carry_out = (R *)c->carry[1];
     p.xcarry_in = last ? nullptr : (const R *)c->carry[2]; p.xcarry_out = (R *)c->carry[3];
-    // a rank that fails in the middle of the pipeline must not leave its neighbours blocked in their receives: it
-    // aborts the group (fs3d_comm_abort), the peers' pending and later exchanges return FS3D_ERR_COMM
-    struct AbortOnError { fs3d_ctx *c; fs3d_status *st; ~AbortOnError() { if (*st != FS3D_OK) fs3d_comm_abort(c); } } guard{c, &st};
     for (int b = 0; b < nb; b++) {
         long long l0, l1; range(b, l0, l1);
         if (l1 <= l0) continue;
@@ -671,19 +684,19 @@ static fs3d_status xsweep_multi(fs3d_ctx *c, SweepParams<R> &p)
 template <typename R>
 static fs3d_status xsweep_reduced(fs3d_ctx *c, SweepParams<R> &p)
 {
-    fs3d_status st = ensure_scratch(c);
-    if (st) return st;
+    fs3d_status st = FS3D_OK;
+    struct AbortOnError { fs3d_ctx *c; fs3d_status *st; ~AbortOnError() { if (*st != FS3D_OK) fs3d_comm_abort(c); } } guard{c, &st};   // peers never block on a rank that failed
+    if (c->nranks > FS3D_XREDUCE_MAX_RANKS) return st = fail(c, FS3D_ERR_UNSUPPORTED, "reduced-interface X solve: more than 64 slabs (k_xreduce holds the slab system in registers); use FS3D_XSOLVE_PIPELINED");
+    if ((st = ensure_scratch(c))) return st;
     p.scr_ = (R *)c->scr;
     const size_t pl = (size_t)c->plane;
-    if (!c->carry[0]) {
-        HIPCHK(c, hipMalloc(&c->carry[0], 6 * pl * c->esize)); HIPCHK(c, hipMalloc(&c->carry[1], 6 * pl * c->esize));
-        HIPCHK(c, hipMalloc(&c->carry[2], 4 * pl * c->esize)); HIPCHK(c, hipMalloc(&c->carry[3], 4 * pl * c->esize));
-    }
+    if ((st = ensure_carries(c))) return st;
     if (!c->xif_send) {
-        HIPCHK(c, hipMalloc(&c->xif_send, 18 * pl * c->esize));
-        HIPCHK(c, hipMalloc(&c->xif_all, (size_t)c->nranks * 18 * pl * c->esize));
+        if (hipMalloc(&c->xif_send, 18 * pl * c->esize) != hipSuccess || hipMalloc(&c->xif_all, (size_t)c->nranks * 18 * pl * c->esize) != hipSuccess) {
+            (void)hipGetLastError();
+            return st = fail(c, FS3D_ERR_HIP, "reduced-interface X solve: hipMalloc of the interface buffers failed");
+        }
     }
-    struct AbortOnError { fs3d_ctx *c; fs3d_status *st; ~AbortOnError() { if (*st != FS3D_OK) fs3d_comm_abort(c); } } guard{c, &st};
     // the slab's interface words: a first pass of the X partition kernel (rows and chunk elimination on chip, 8 words per cell
     // read, 18 words per line written) where it applies, else the thread-per-line walk over the planes
     bool iface_done = false;
@@ -783,7 +796,7 @@ static fs3d_status sweep_buffers(fs3d_ctx *c, int dir, double dt, int b_cur, int
     // what one rank computes)
     if (dir == 0 && (c->nranks > 1 || (c->opt_xsolve == 2 && (p.ghost_lo || p.ghost_hi)))) {
         // reduced-interface form (all ranks at once) unless bit-equality with the sequential recurrence was asked for
-        const bool reduced = c->opt_xsolve == 2 || (c->opt_xsolve == 0 && (c->opt_kernel == FS3D_SWEEP_AUTO || c->opt_kernel == FS3D_SWEEP_PART));
+        const bool reduced = c->opt_xsolve == 2 || (c->opt_xsolve == 0 && c->nranks <= FS3D_XREDUCE_MAX_RANKS && (c->opt_kernel == FS3D_SWEEP_AUTO || c->opt_kernel == FS3D_SWEEP_PART));
         fs3d_status st = reduced ? xsweep_reduced<R>(c, p) : xsweep_multi<R>(c, p);
         rec_end(c);
         if (st) return st;

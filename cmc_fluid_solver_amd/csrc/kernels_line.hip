@@ -256,7 +256,7 @@ __global__ void __launch_bounds__(256) k_xiface(SweepParams<R> p, R *out)
     o[14 * nl] = ep[0]; o[15 * nl] = ep[1]; o[16 * nl] = ep[2]; o[17 * nl] = ep[3];
 }
 
-#define XREDUCE_MAXR 64
+#define XREDUCE_MAXR FS3D_XREDUCE_MAX_RANKS      // larger groups: refused (explicit) / pipelined form (auto), fs3d_hip.hip
 template <typename R>
 __global__ void __launch_bounds__(256) k_xreduce(const R *all, long long nl, int nranks, int me, R *carry_in, R *xcarry_in)
 {

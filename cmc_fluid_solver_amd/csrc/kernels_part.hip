@@ -42,14 +42,35 @@ typedef unsigned pu32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned pu32x4 __attribute__((ext_vector_type(4)));
 #define PART_OOB 0xFFFFFFFFu      // voffset >= num_records: the hardware drops the store / returns 0 for the load
 
+// Cache policy of the streams (the `aux` operand of the raw buffer intrinsics on gfx94x/gfx950: 1 = sc0, 2 = nt, 16 = sc1).
+// `cur` is read exactly once per sweep, `next` / `temp_out` are written once and read again only by the NEXT launch, a gigabyte
+// later: nontemporal.  X/Y kernels: the main `temp` loads stay cached -- the o+-1 rows of the neighbouring workgroups and the
+// second read of the store phase are served from them (nt there: X +6 %, Y +3 % slower).  Z kernel: nt on every stream.
+// Measured (profiles/r3_ab_nt.txt, one box, interleaved, per launch with all stores): X 0.300 -> 0.279, Y 0.272 -> 0.248,
+// Z 0.242 -> 0.219 ms; tools/ubench/stream2.hip: nt loads read at 7.0 instead of 6.0-6.2 TB/s.
+#ifndef FS3D_PART_AUX_CUR
+#define FS3D_PART_AUX_CUR 2
+#endif
+#ifndef FS3D_PART_AUX_TMP
+#define FS3D_PART_AUX_TMP 0
+#endif
+#ifndef FS3D_PART_AUX_ST
+#define FS3D_PART_AUX_ST 2
+#endif
+#ifndef FS3D_PARTZ_AUX_TMP
+#define FS3D_PARTZ_AUX_TMP 2
+#endif
+#ifndef FS3D_PARTZ_AUX_W
+#define FS3D_PARTZ_AUX_W 0        // W of the line itself: the rows j+-1 and planes i+-1 read it again as their neighbour
+#endif
 template <typename R> struct PBuf;
 template <> struct PBuf<float> {
-    static __device__ __forceinline__ float ld(prsrc_t r, unsigned vo, unsigned so) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, vo, so, 0)); }
-    static __device__ __forceinline__ void st(prsrc_t r, unsigned vo, unsigned so, float v) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, vo, so, 0); }
+    template <int AUX = 0> static __device__ __forceinline__ float ld(prsrc_t r, unsigned vo, unsigned so) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, vo, so, AUX)); }
+    template <int AUX = 0> static __device__ __forceinline__ void st(prsrc_t r, unsigned vo, unsigned so, float v) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, vo, so, AUX); }
 };
 template <> struct PBuf<double> {
-    static __device__ __forceinline__ double ld(prsrc_t r, unsigned vo, unsigned so) { return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, vo, so, 0)); }
-    static __device__ __forceinline__ void st(prsrc_t r, unsigned vo, unsigned so, double v) { __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(pu32x2, v), r, vo, so, 0); }
+    template <int AUX = 0> static __device__ __forceinline__ double ld(prsrc_t r, unsigned vo, unsigned so) { return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, vo, so, AUX)); }
+    template <int AUX = 0> static __device__ __forceinline__ void st(prsrc_t r, unsigned vo, unsigned so, double v) { __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(pu32x2, v), r, vo, so, AUX); }
 };
 
 // reciprocal: v_rcp_f32 (1 ulp) + one Newton step
@@ -173,7 +194,11 @@ __global__ void __launch_bounds__(LT * NCH, WPS) k_sweep_part(SweepParams<R> p, 
     }
     // order 0: consecutive ids = consecutive rows/planes `o` of one lane tile; 1: = the lane tiles of one row/plane
     // (concurrently running workgroups then stream whole rows: DRAM page locality)
+#ifdef FS3D_EXPERIMENTS              // timing experiments only (WRONG NUMBERS): never compiled into libfs3d_hip.so (build.build_variant only)
     const bool x_nonb = order & 2, x_nore = order & 4;
+#else
+    constexpr bool x_nonb = false, x_nore = false;
+#endif
     if (order & 8) {                                      // experiment: the later waves of the workgroup first during P
         const int wq = (t >> 6) * 4 / (LT * NCH / 64);
         if (wq == 1) __builtin_amdgcn_s_setprio(1); else if (wq == 2) __builtin_amdgcn_s_setprio(2); else if (wq == 3) __builtin_amdgcn_s_setprio(3);
@@ -234,9 +259,9 @@ __global__ void __launch_bounds__(LT * NCH, WPS) k_sweep_part(SweepParams<R> p, 
         const unsigned sc = s_is;
         s_is = opq_s(s_is + ssb);
 #pragma unroll
-        for (int f = 0; f < 4; f++) L.tp[f] = PBuf<R>::ld(Ltmp, vo, sc + ssb + (unsigned)f * fsb);
+        for (int f = 0; f < 4; f++) L.tp[f] = PBuf<R>::template ld<FS3D_PART_AUX_TMP>(Ltmp, vo, sc + ssb + (unsigned)f * fsb);
 #pragma unroll
-        for (int f = 0; f < 4; f++) L.c[f] = PBuf<R>::ld(Lcur, vo, sc + (unsigned)f * fsb);
+        for (int f = 0; f < 4; f++) L.c[f] = PBuf<R>::template ld<FS3D_PART_AUX_CUR>(Lcur, vo, sc + (unsigned)f * fsb);
         const unsigned sv = sc + (unsigned)DIR * fsb;
         if (x_nonb) { L.om = L.op = L.le = L.c[0]; }
         else {
@@ -565,7 +590,7 @@ __global__ void __launch_bounds__(LT * NCH, WPS) k_sweep_part(SweepParams<R> p, 
             if (p.store_next) {
                 const unsigned v_ = seg ? vo_st : PART_OOB;            // UpdateSegment: every cell of a segment, nothing else
 #pragma unroll
-                for (int f = 0; f < 4; f++) PBuf<R>::st(Lnext, v_, sc + (unsigned)f * fsb, xv[f]);
+                for (int f = 0; f < 4; f++) PBuf<R>::template st<FS3D_PART_AUX_ST>(Lnext, v_, sc + (unsigned)f * fsb, xv[f]);
             }
             if (p.merge) {
                 R tq[4];
@@ -582,7 +607,7 @@ __global__ void __launch_bounds__(LT * NCH, WPS) k_sweep_part(SweepParams<R> p, 
                 for (int f = 0; f < 4; f++) {
                     R mv = (tq[f] + xv[f]) * R(0.5);                                   // MergeFieldTo (TimeLayer3D.h:415-436)
                     if (p.merge == 2) mv = (mv + xv[f]) * R(0.5);
-                    PBuf<R>::st(Ltout, v_, sc + (unsigned)f * fsb, isin ? mv : tq[f]);
+                    PBuf<R>::template st<FS3D_PART_AUX_ST>(Ltout, v_, sc + (unsigned)f * fsb, isin ? mv : tq[f]);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -592,13 +617,21 @@ __global__ void __launch_bounds__(LT * NCH, WPS) k_sweep_part(SweepParams<R> p, 
 #undef PSTAMP
 }
 
+// Kernel-experiment knobs (tile order, start delays, LDS padding, ...; FS3D_PART_ORDER bits 1/2 skip loads and give WRONG numbers):
+// read from the environment only in -DFS3D_EXPERIMENTS builds (build.build_variant); libfs3d_hip.so compiles the defaults in.
+#ifdef FS3D_EXPERIMENTS
+static int part_exp_env(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
+#else
+static constexpr int part_exp_env(const char *, int dflt) { return dflt; }
+#endif
+
 template <typename R, int DIR, int M, int NCH, int WPS, int LT, int PF = FS3D_PART_PF, int XB = 0, int OPF = FS3D_PART_OPF, bool KT = false>
 static bool part_launch_xy(fs3d_ctx *c, const SweepParams<R> &p)
 {
     const int n_o = DIR == 0 ? p.dimy : (p.o_count ? p.o_count : p.dimx);
     const int n_tiles = (p.dimz + LT - 1) / LT;
     // FS3D_PART_LDSPAD (kernel experiments): more dynamic LDS than needed, to hold the workgroups per CU down
-    static const size_t lds_pad = getenv("FS3D_PART_LDSPAD") ? (size_t)atoi(getenv("FS3D_PART_LDSPAD")) : 0;
+    static const size_t lds_pad = (size_t)part_exp_env("FS3D_PART_LDSPAD", 0);
     const size_t lds = ((size_t)NCH * M * LT + (size_t)(PART_EXW + (NCH > 16 ? 4 : 0)) * NCH * LT) * sizeof(R) + lds_pad;
     static std::atomic<unsigned long long> attr_set{0};
     const unsigned long long dev_bit = 1ull << (c->device & 63);
@@ -611,13 +644,13 @@ static bool part_launch_xy(fs3d_ctx *c, const SweepParams<R> &p)
     }
     // workgroup order: 32-line tiles run the lane tiles of one row/plane on consecutive workgroups (the 128-byte pieces of a
     // row are then fetched together: 512^3 X 2.93 -> 2.71 ms, Y 2.18 -> 2.10), 64-line tiles the rows/planes of one lane tile
-    static const int order_env = getenv("FS3D_PART_ORDER") ? atoi(getenv("FS3D_PART_ORDER")) : -1;   // kernel experiments
+    static const int order_env = part_exp_env("FS3D_PART_ORDER", -1);
     // 32-line tiles, two workgroups per CU: the second workgroup of every CU starts ~16 us late, so that the two do not load,
     // solve and store at the same time (tools/ab_tiles.py, interleaved on one box: 64 lines 6.12 ms per step, 32 lines 5.81,
     // 32 lines with the late start 5.63-5.66).  Few workgroups (thin slabs) and 512-cell lines: lane tiles fastest.
     // (the late start only where it was measured: 512-thread workgroups, two per CU, at least two generations of them)
     const bool late = LT == 32 && NCH == 16 && M == 16 && (long long)n_o * n_tiles >= 1024;
-    static const int late_slab = getenv("FS3D_PART_LATE_SLAB") ? atoi(getenv("FS3D_PART_LATE_SLAB")) : 0;   // experiment: slab kernels (XB != 0), delay units
+    static const int late_slab = part_exp_env("FS3D_PART_LATE_SLAB", 0);   // experiment: slab kernels (XB != 0), delay units
     int order = order_env >= 0 ? order_env : (LT == 32 ? (((long long)n_o * n_tiles < 1024 || NCH == 32) ? 1 : 0) | (late ? 0x40 | (4 << 8) : 0) : 0);
     if (XB != 0 && late_slab > 0 && LT * NCH <= 512 && (long long)n_o * n_tiles >= 512) order |= 0x40 | (late_slab << 8);
     hipLaunchKernelGGL((k_sweep_part<R, DIR, M, NCH, WPS, LT, PF, XB, OPF, KT>), dim3((unsigned)(n_o * n_tiles)), dim3(LT * NCH), lds, c->stream, p, n_o, n_tiles, order);
@@ -630,7 +663,7 @@ static bool part_dispatch_xy(fs3d_ctx *c, const SweepParams<R> &p)
     const int n = DIR == 0 ? p.dimx : p.dimy;
     if (n < 4) return false;
     if constexpr (std::is_same<R, float>::value) {       // fp64 contexts run the exact kernels
-        static const int variant = getenv("FS3D_PART_VARIANT") ? atoi(getenv("FS3D_PART_VARIANT")) : 0;   // kernel experiments
+        static const int variant = getenv("FS3D_PART_VARIANT") ? atoi(getenv("FS3D_PART_VARIANT")) : 0;   // other tilings of the same arithmetic (result-neutral: tested)
         if (DIR == 0 && p.xiface_pass) {
             // first pass of the cross-slab sweep: the slab's interface words (whole chunks only)
             constexpr int D0 = 0;
@@ -661,9 +694,6 @@ static bool part_dispatch_xy(fs3d_ctx *c, const SweepParams<R> &p)
             if (variant == 10) return part_launch_xy<R, DIR, 8, 32, 4, 32, 2, false, 2, true>(c, p);   // 8 cells per thread, 32 lines, the temp values
                                                                                                     // stay in registers for the merge: 1.1x slower
                                                                                                     // (without keeping them: 1.25x)
-            // thin slabs (a 32-plane x-slab of the 256^3 box: 32 x 4 workgroups of 64 lines for 256 CUs): 32-line
-            // workgroups, twice as many
-            const int n_o = DIR == 0 ? p.dimy : p.dimx;
             // 64 lines x 16 chunks (one workgroup of 1024 threads per CU, 256-byte row pieces) was the default until the layer fields
             // were padded; since then two 32-line workgroups per CU are faster (their phases overlap inside the CU)
             if (variant == 64) return part_launch_xy<R, DIR, 16, 16, 4, 64>(c, p);
@@ -686,18 +716,20 @@ static bool part_dispatch_xy(fs3d_ctx *c, const SweepParams<R> &p)
 // -> x to `next`, merged temp to `temp_out`; the temp values needed by the merge are still in registers.
 typedef float pf4 __attribute__((ext_vector_type(4)));
 struct PV4 { float v[4]; };
+template <int AUX = 0>
 __device__ __forceinline__ PV4 pld4(prsrc_t r, unsigned vo, unsigned so)
 {
-    const pu32x4 q = __builtin_amdgcn_raw_buffer_load_b128(r, vo, so, 0);
+    const pu32x4 q = __builtin_amdgcn_raw_buffer_load_b128(r, vo, so, AUX);
     PV4 o;
     __builtin_memcpy(o.v, &q, 16);
     return o;
 }
+template <int AUX = 0>
 __device__ __forceinline__ void pst4(prsrc_t r, unsigned vo, unsigned so, const float (&v)[4])
 {
     pu32x4 q;
     __builtin_memcpy(&q, v, 16);
-    __builtin_amdgcn_raw_buffer_store_b128(q, r, vo, so, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(q, r, vo, so, AUX);
     // A 16-byte store reads its data registers a few cycles after it issues.  hipcc pads a following VALU write of
     // those registers only for stores without a scalar offset; here (SGPR soffset) it reused them two instructions
     // later and the first dword of the NEXT field's data reached memory (seen on gfx950: sporadic, last lanes of a
@@ -771,10 +803,10 @@ __global__ void __launch_bounds__(256, WPS) k_sweep_part_z(SweepParams<float> p,
         // jrow: first line of the row (wave-uniform); this lane's line is jrow + sub, clamped into the plane for the loads
         const int jr = jrow < p.dimy ? jrow : p.dimy - 1;   // a row past the plane (tail of the last group): valid addresses, nothing stored
         const unsigned so = opq_s(line_so(jr));
-        L.tc[2] = pld4(Ltmp, vo_l, so + 2u * fsb);       // W first: the row before needs it as its j+1 neighbour... and the stencils
-        L.tc[0] = pld4(Ltmp, vo_l, so); L.tc[1] = pld4(Ltmp, vo_l, so + fsb); L.tc[3] = pld4(Ltmp, vo_l, so + 3u * fsb);
+        L.tc[2] = pld4<FS3D_PARTZ_AUX_W>(Ltmp, vo_l, so + 2u * fsb);       // W first: the row before needs it as its j+1 neighbour... and the stencils
+        L.tc[0] = pld4<FS3D_PARTZ_AUX_TMP>(Ltmp, vo_l, so); L.tc[1] = pld4<FS3D_PARTZ_AUX_TMP>(Ltmp, vo_l, so + fsb); L.tc[3] = pld4<FS3D_PARTZ_AUX_TMP>(Ltmp, vo_l, so + 3u * fsb);
 #pragma unroll
-        for (int f = 0; f < 4; f++) L.cu[f] = pld4(Lcur, vo_l, so + (unsigned)f * fsb);
+        for (int f = 0; f < 4; f++) L.cu[f] = pld4<FS3D_PART_AUX_CUR>(Lcur, vo_l, so + (unsigned)f * fsb);
         L.wim = pld4(Ltmp, vo_l, so + 2u * fsb - planeb); L.wip = pld4(Ltmp, vo_l, so + 2u * fsb + planeb);
         if (LI > 1) { L.wjm = pld4(Ltmp, vo_l, so + 2u * fsb - rowb); L.wjp = pld4(Ltmp, vo_l, so + 2u * fsb + rowb); }
         const unsigned son = opq_s(line_son(jr));
@@ -967,7 +999,7 @@ __global__ void __launch_bounds__(256, WPS) k_sweep_part_z(SweepParams<float> p,
         if (p.store_next) {
             if (__all(all_seg || !st_ok)) {
 #pragma unroll
-                for (int f = 0; f < 4; f++) pst4(Lnext, vo_st, so + (unsigned)f * fsb, x[f]);
+                for (int f = 0; f < 4; f++) pst4<FS3D_PART_AUX_ST>(Lnext, vo_st, so + (unsigned)f * fsb, x[f]);
             } else {
 #pragma unroll
                 for (int f = 0; f < 4; f++)
@@ -998,7 +1030,7 @@ __global__ void __launch_bounds__(256, WPS) k_sweep_part_z(SweepParams<float> p,
                     if (p.merge == 2) mvv = (mvv + x[f][c]) * R(0.5);
                     o4[c] = isin[c] ? mvv : L.tc[f].v[c];
                 }
-                pst4(Ltout, vo_st, so + (unsigned)f * fsb, o4);
+                pst4<FS3D_PART_AUX_ST>(Ltout, vo_st, so + (unsigned)f * fsb, o4);
             }
         }
     };
@@ -1057,7 +1089,7 @@ template <int LPL, int NW = 1>
 static bool part_launch_z(fs3d_ctx *c, const SweepParams<float> &p)
 {
     constexpr int LI = 64 / LPL;
-    static const int lg_env = getenv("FS3D_PART_ZLG") ? atoi(getenv("FS3D_PART_ZLG")) : 0;     // kernel experiments
+    static const int lg_env = part_exp_env("FS3D_PART_ZLG", 0);
     const int rows = (p.dimy + LI - 1) / LI;              // rows of LI lines per plane
     const int npl = p.o_count ? p.o_count : p.dimx;
     // 8 rows per wave where the grid is large enough to give every CU several workgroups that way; fewer on small grids /

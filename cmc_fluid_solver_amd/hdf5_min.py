@@ -168,14 +168,18 @@ class Hdf5File:
             out[sel_o] = chunk[sel_c]
         return out
 
-    def _chunks(self, addr, rank):
+    def _chunks(self, addr, rank, parent_level=-1, depth=0):
         d = self.d
         p = self.base + addr
-        if d[p:p + 4] != b"TREE" or d[p + 4] != 1:
+        if depth > 8 or p + 24 > len(d) or d[p:p + 4] != b"TREE" or d[p + 4] != 1:
             raise Hdf5Error("version-1 B-tree of raw data chunks expected")
         level, n = d[p + 5], struct.unpack("<H", d[p + 6:p + 8])[0]
+        if parent_level >= 0 and level != parent_level - 1:          # a node that names itself must not recurse for ever
+            raise Hdf5Error("B-tree child is not one level below its parent")
         p += 24
         ks = 8 + 8 * (rank + 1)
+        if p + n * (ks + 8) > len(d):
+            raise Hdf5Error("B-tree node past the end of the file")
         for _ in range(n):
             size, mask = struct.unpack("<II", d[p:p + 8])
             offs = struct.unpack("<%dQ" % rank, d[p + 8:p + 8 + 8 * rank])
@@ -184,4 +188,4 @@ class Hdf5File:
             if level == 0:
                 yield offs, child, size, mask
             else:
-                yield from self._chunks(child, rank)
+                yield from self._chunks(child, rank, level, depth + 1)

@@ -52,8 +52,8 @@ class Hdf5File {
     std::vector<Msg> messages(uint64_t addr) const
     {
         size_t a = (size_t)(addr + base_);
-        if (!sig(a, "OHDR") || d_[a + 4] != 2) throw std::runtime_error("HDF5: object header version 2 expected");
-        const int flags = d_[a + 5];
+        if (!sig(a, "OHDR") || u(a + 4, 1) != 2) throw std::runtime_error("HDF5: object header version 2 expected");
+        const int flags = (int)u(a + 5, 1);
         size_t p = a + 6;
         if (flags & 0x20) p += 16;
         if (flags & 0x10) p += 4;
@@ -104,20 +104,24 @@ class Hdf5File {
     }
 
     struct Chunk { std::vector<uint64_t> offs; uint64_t addr; uint32_t size, mask; };
-    void chunks(uint64_t addr, int rank, std::vector<Chunk> &out) const
+    // B-tree of the raw data chunks.  Level and child addresses come from the file: the walk is bounded (a child must be one
+    // level below its parent, at most 8 levels, entries must fit the file) so that a node that names itself cannot recurse for ever.
+    void chunks(uint64_t addr, int rank, std::vector<Chunk> &out, int parent_level = -1, int depth = 0) const
     {
         size_t p = (size_t)(addr + base_);
-        if (!sig(p, "TREE") || d_[p + 4] != 1) throw std::runtime_error("HDF5: version-1 B-tree of raw data chunks expected");
-        const int level = d_[p + 5], n = (int)u(p + 6, 2);
+        if (depth > 8 || !sig(p, "TREE") || u(p + 4, 1) != 1) throw std::runtime_error("HDF5: version-1 B-tree of raw data chunks expected");
+        const int level = (int)u(p + 5, 1), n = (int)u(p + 6, 2);
+        if (parent_level >= 0 && level != parent_level - 1) throw std::runtime_error("HDF5: B-tree child is not one level below its parent");
         p += 24;
         const size_t ks = 8 + 8 * (size_t)(rank + 1);
+        if (p + (size_t)n * (ks + 8) > d_.size()) throw std::runtime_error("HDF5: B-tree node past the end of the file");
         for (int e = 0; e < n; e++) {
             Chunk c;
             c.size = (uint32_t)u(p, 4); c.mask = (uint32_t)u(p + 4, 4);
             for (int k = 0; k < rank; k++) c.offs.push_back(u(p + 8 + 8 * k, 8));
             c.addr = u(p + ks, 8);
             p += ks + 8;
-            if (level == 0) out.push_back(c); else chunks(c.addr, rank, out);
+            if (level == 0) out.push_back(c); else chunks(c.addr, rank, out, level, depth + 1);
         }
     }
 
@@ -144,6 +148,7 @@ public:
             if (fl & 0x10) p += 1;
             const int n = 1 << (fl & 3);
             const size_t ln = (size_t)u(p, n); p += n;
+            if (p + ln + 8 > d_.size()) throw std::runtime_error("HDF5: link name past the end of the file");
             const std::string name((const char *)&d_[p], ln); p += ln;
             if (ltype == 0) links_[name] = u(p, 8);
         }

@@ -177,12 +177,17 @@ def load_shape3d(path_or_text, dx, dy, dz, baseT=1.0, align=True, is_text=False)
     """Grid3D(dx,dy,dz,baseT) + LoadFromFile + Prepare_CPU(0) for a Shape3D input -> (Nodes, Shape3D)."""
     text = path_or_text if is_text else open(path_or_text, "r").read()
     sh = Shape3D(parse_shape3d(text), dx, dy, dz, align)
+    return nodes_of(sh, dx, dy, dz, baseT), sh
+
+
+def nodes_of(sh, dx, dy, dz, baseT=1.0):
+    """The Node array of a prepared Shape3D grid: NODE_BOUND cells carry NOSLIP, v = 0, T = 0 (what the reference's run holds
+    there: tests/golden/ref_box_pipe_3D_f32.npz), every other cell T = baseT."""
     shape = sh.type.shape
     z8 = np.zeros(shape, np.uint8)
     zero = np.zeros(shape, np.float64)
     T = np.where(sh.type == NODE_BOUND, 0.0, float(F(baseT)))
-    nodes = Nodes(sh.dimx, sh.dimy, sh.dimz, dx, dy, dz, sh.type.copy(), z8 + BC_NOSLIP, z8 + BC_NOSLIP, zero, zero.copy(), zero.copy(), T)
-    return nodes, sh
+    return Nodes(sh.dimx, sh.dimy, sh.dimz, dx, dy, dz, sh.type.copy(), z8 + BC_NOSLIP, z8 + BC_NOSLIP, zero, zero.copy(), zero.copy(), T)
 
 
 def write_mesh(path, frames):

@@ -28,8 +28,8 @@ def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
     srcs = [os.path.join(_HERE, f) for f in ("fs3d_oracle.c", "fs3d_oracle_body.inc")]
     stale = (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
-    ref_srcs = [os.path.join(_HERE, f) for f in ("ref_harness_f32.cpp", "ref_harness_f64.cpp", "ref_harness_cfg.cpp", "ref_harness_adi.cpp")]
-    ref_sos = [os.path.join(_HERE, "_ref", f) for f in ("libref_pieces.so", "libref_config.so", "ref_adi_f32", "ref_adi_f64")]
+    ref_srcs = [os.path.join(_HERE, f) for f in ("ref_harness_f32.cpp", "ref_harness_f64.cpp", "ref_harness_cfg.cpp", "ref_harness_adi.cpp", "ref_harness_2d.cpp")]
+    ref_sos = [os.path.join(_HERE, "_ref", f) for f in ("libref_pieces.so", "libref_config.so", "ref_adi_f32", "ref_adi_f64", "ref_stable2d")]
     ref_missing = os.path.isdir("/root/reference/src/Common") and (
         not all(os.path.exists(p) for p in ref_sos) or any(os.path.getmtime(s) > min(os.path.getmtime(p) for p in ref_sos) for s in ref_srcs))
     if force or stale or ref_missing:

@@ -110,3 +110,46 @@ def read_dump(path, ft):
     assert o == len(b)
     return {"dims": dims, "frames": frames, "dx": dx, "dy": dy, "dz": dz, "dt": dt, "cycle_length": length,
             "params": (vT, vvis, tvis, tphi), "nodes": nodes, "grid_at": grid_at, "steps": steps, "layers": layers}
+
+
+def binary2d():
+    p = os.path.join(_HERE, "_ref", "ref_stable2d")
+    return p if os.path.exists(p) else None
+
+
+def run2d(data_path, config_text, max_steps, dump_steps, timeout=1800):
+    """The reference's Grid2D + StableSolver2D (oracle/ref_harness_2d.cpp) -> dict(dims, frames, dx, dy, dt, cycle_length, v_vis,
+    steps{s: {type, U, V, T}}, stdout)."""
+    exe = binary2d()
+    if exe is None:
+        raise RuntimeError("oracle/_ref/ref_stable2d not built (make -C oracle ref_full needs /root/reference)")
+    tmp = tempfile.mkdtemp(prefix="refrun2d_")
+    try:
+        d, c, out = (os.path.join(tmp, n) for n in ("data.txt", "config.txt", "dump.bin"))
+        strip_cr(data_path, d)
+        with open(c, "w") as f:
+            f.write(config_text.replace("\r", ""))
+        p = subprocess.run([exe, d, c, out, str(int(max_steps)), ",".join(str(int(s)) for s in dump_steps) or "-"],
+                           capture_output=True, text=True, timeout=timeout, cwd=tmp)
+        if p.returncode != 0 or not os.path.exists(out):
+            raise RuntimeError("reference 2D run failed (rc %d)\n%s\n%s" % (p.returncode, p.stdout[-2000:], p.stderr[-2000:]))
+        with open(out, "rb") as f:
+            b = f.read()
+        assert b[:8] == b"FS2DREF1"
+        fsz, dimx, dimy, frames = struct.unpack_from("<4i", b, 8)
+        dx, dy, dt, length, v_vis = struct.unpack_from("<5d", b, 24)
+        assert fsz == 4
+        o, n, steps = 64, dimx * dimy, {}
+        while True:
+            (s,) = struct.unpack_from("<i", b, o); o += 4
+            if s < 0:
+                break
+            st = {"type": np.frombuffer(b, np.uint8, n, o).reshape(dimx, dimy).copy()}; o += n
+            for v in "UVT":
+                st[v] = np.frombuffer(b, np.float32, n, o).reshape(dimx, dimy).copy(); o += 4 * n
+            steps[s] = st
+        assert o == len(b)
+        return {"dims": (dimx, dimy), "frames": frames, "dx": dx, "dy": dy, "dt": dt, "cycle_length": length, "v_vis": v_vis,
+                "steps": steps, "stdout": p.stdout, "err_trace": [float(m) for m in re.findall(r"err = ([0-9.]+),", p.stdout)]}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)

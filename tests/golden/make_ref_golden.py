@@ -74,6 +74,16 @@ CASES = {
     # multi-frame Shape2D (moving walls + valve): adapted config (the shipped one is rejected by the reference's parser)
     "heart_us": dict(data="heart_us_2D_data.txt", config="heart_us_2D_config.txt", keys={}, align=True, prec=("f32",),
                      steps=8, full={}, hashed=(1, 2, 3, 4, 8), stride=2, grid_times="frames"),
+    # Shape3D inputs (triangle meshes): the shipped box_pipe_3D and tetra examples -- their shipped config names no out_vars and no
+    # frame_time, which the reference's parser / time loop need: both keys appended (tests/golden/inputs/box_pipe_3D_config.txt);
+    # tetra diverges in the reference itself at step 9 ("Error is too big!"): 5 steps
+    "box_pipe_3D": dict(data="box_pipe_3D_data.txt", config="box_pipe_3D_config.txt", keys=dict(out_gridx="32", out_gridy="32", out_gridz="32"),
+                        align=True, prec=("f32",), steps=10, full={}, hashed=(1, 2, 10), stride=4),
+    "tetra": dict(data="tetra_data.txt", config="box_pipe_3D_config.txt", keys=dict(out_gridx="32", out_gridy="16", out_gridz="16"),
+                  align=True, prec=("f32",), steps=5, full={}, hashed=(1, 2, 5), stride=2),
+    # authored two-frame icosphere (tests/test_shape3d.py: 80 faces, none axis-aligned, the second frame shifted): moving mesh
+    "sphere_3D": dict(data="sphere_3D_data.txt", config="sphere_3D_config.txt", keys={}, align=True, prec=("f32", "f64"), steps=7,
+                      full={"f32": (1, 7)}, hashed=(1, 2, 7), stride=0, grid_times=(0.0, 0.1, 0.2, 0.3, 0.5)),
 }
 
 
@@ -108,8 +118,14 @@ def make(name, case):
             probe = refdump.run(os.path.join(INP, case["data"]), cfg_text, ft, 0, [], case["align"])
             fr, ln = probe["frames"], probe["cycle_length"]
             gt = [0.0, 0.25 * ln / fr, 0.5 * ln / fr, 1.0 * ln / fr, 1.5 * ln / fr, (fr - 0.5) * ln / fr]
+        elif case.get("grid_times"):
+            gt = list(case["grid_times"])
         t0 = time.time()
-        r = refdump.run(os.path.join(INP, case["data"]), cfg_text, ft, case["steps"], dumps, case["align"], gt)
+        # the geometry at other times comes from a run of its own (no steps): Prepare_CPU(t) leaves traces in the Node array
+        # (Shape3D: cells that were NODE_BOUND at time t keep T = 0 when they are fluid again), the stepping run must not see them
+        r = refdump.run(os.path.join(INP, case["data"]), cfg_text, ft, case["steps"], dumps, case["align"])
+        if len(gt):
+            r["grid_at"] = refdump.run(os.path.join(INP, case["data"]), cfg_text, ft, 0, [], case["align"], gt)["grid_at"]
         out, meta = compact_nodes(r["nodes"], ft)
         meta.update(case=name, data=case["data"], config_text=cfg_text, align=case["align"], prec=prec, dims=list(r["dims"]),
                     frames=r["frames"], dx=r["dx"], dy=r["dy"], dz=r["dz"], dt=r["dt"], cycle_length=r["cycle_length"],
@@ -147,9 +163,59 @@ def make(name, case):
                                                                       r["dims"], meta["node_in"], r["err_trace"][-1:]), flush=True)
 
 
+# ---- the 2D path (f4): the reference's own Grid2D + StableSolver2D (oracle/ref_harness_2d.cpp) ------------------------------------
+HEART2D = """dimension\t2D
+viscosity \t0.004
+density \t1.0
+bc_type\t\tNoSlip
+grid_dx\t\t0.0007
+grid_dy\t\t0.0007
+cycles \t\t1
+time_steps \t400
+out_time_steps \t2
+out_gridx\t32
+out_gridy \t32
+out_fmt\t\tNetCDF
+solver\t\tStable
+num_global \t2
+num_local \t1
+"""
+CASES2D = {
+    # the authored lid-driven cavity (BASELINE configs[0]) as configured: 128 x 128
+    "cavity128": dict(data="cavity_2D_data.txt", config="cavity_2D_config.txt", keys={}, steps=(1, 2)),
+    # the same cavity at 54 x 54, one global iteration
+    "cavity54": dict(data="cavity_2D_data.txt", config="cavity_2D_config.txt",
+                     keys=dict(grid_dx="0.0199", grid_dy="0.0199", time_steps="200", out_time_steps="1", out_gridx="27", out_gridy="27", num_global="1"),
+                     steps=(1, 2, 3)),
+    # moving walls: the 10-frame heart_us outline as a 2D problem (grid.Prepare(t) every step); with fewer than ~400 steps per frame
+    # the reference's Stable solver stops with "Error is too big!" at the first step
+    "heart2d": dict(data="heart_us_2D_data.txt", config_text=HEART2D, keys={}, steps=(1, 2, 4)),
+}
+
+
+def make2d(name, case):
+    cfg_text = case.get("config_text") or set_keys(open(os.path.join(INP, case["config"])).read(), **case["keys"])
+    t0 = time.time()
+    r = refdump.run2d(os.path.join(INP, case["data"]), cfg_text, max(case["steps"]), case["steps"])
+    out = {}
+    for st, rec in r["steps"].items():
+        for k in ("type", "U", "V", "T"):
+            out["%s_step%d" % (k, st)] = rec[k]
+    meta = dict(case=name, data=case["data"], config_text=cfg_text, dims=list(r["dims"]), frames=r["frames"], dx=r["dx"], dy=r["dy"], dt=r["dt"],
+                cycle_length=r["cycle_length"], v_vis=r["v_vis"], err_trace=r["err_trace"], steps=list(case["steps"]),
+                generator="tests/golden/make_ref_golden.py; oracle/_ref/ref_stable2d = the reference's Grid2D + StableSolver2D as they lie")
+    out["meta"] = np.array(json.dumps(meta))
+    fn = os.path.join(HERE, "ref2d_%s.npz" % name)
+    np.savez_compressed(fn, **out)
+    print("%-40s %8.1f KB  %5.1f s  dims %s  err %s" % (os.path.basename(fn), os.path.getsize(fn) / 1e3, time.time() - t0, r["dims"], r["err_trace"]), flush=True)
+
+
 if __name__ == "__main__":
     if not refdump.available():
         sys.exit("oracle/_ref/ref_adi_f32|f64 missing: run `make -C oracle ref_full` (needs /root/reference)")
-    names = sys.argv[1:] or list(CASES)
+    names = sys.argv[1:] or list(CASES) + list(CASES2D)
     for nm in names:
-        make(nm, CASES[nm])
+        if nm in CASES2D:
+            make2d(nm, CASES2D[nm])
+        else:
+            make(nm, CASES[nm])

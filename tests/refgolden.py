@@ -19,7 +19,7 @@ INP = os.path.join(GOLD, "inputs")
 
 ALL = [("u_bend", "f32"), ("u_bend", "f64"), ("box_pipe", "f32"), ("box_pipe", "f64"), ("non_uniform_pipe", "f32"),
        ("non_uniform_pipe", "f64"), ("box128", "f32"), ("box128", "f64"), ("box256", "f32"), ("non_uniform256", "f32"),
-       ("heart_us", "f32")]
+       ("heart_us", "f32"), ("box_pipe_3D", "f32"), ("tetra", "f32"), ("sphere_3D", "f32"), ("sphere_3D", "f64")]
 
 
 def sha(a):
@@ -71,8 +71,15 @@ class Fixture:
         return grids.Nodes(self.dims[0], self.dims[1], self.dims[2], m["dx"], m["dy"], m["dz"], ty, z["node_bc_vel"], z["node_bc_temp"],
                            fields["vx"], fields["vy"], fields["vz"], fields["T"])
 
-    def loader(self):
-        """(Nodes, Config, dt) through THIS repo's Shape2D loader from the same input files."""
+    def loader(self, time=0.0):
+        """(Nodes, Config, dt) through THIS repo's Shape2D / Shape3D loader from the same input files."""
+        cfg = self.cfg()
+        if cfg.in_fmt == "Shape3D":
+            from cmc_fluid_solver_amd import shape3d
+            text = open(self.data_path).read()
+            sh = shape3d.Shape3D(shape3d.parse_shape3d(text), cfg.dx, cfg.dy, cfg.dz, self.meta["align"], time)
+            nodes = shape3d.nodes_of(sh, cfg.dx, cfg.dy, cfg.dz, cfg.baseT)
+            return nodes, cfg, cfg.frame_time / (len(sh.frames) * cfg.time_steps)       # GetCycleLength() = frame_time (Grid3D.cpp:303-336)
         p = self.config_path()
         try:
             return shape2d.load_case(self.data_path, p, align=self.meta["align"])
@@ -85,8 +92,15 @@ class Fixture:
     def schedule(self, max_steps=None):
         """[(step, compute_error, output_layer)] -- FluidSolver3D.cpp:226-262 (substep counter restarts at every frame)."""
         cfg = self.cfg()
-        g2 = shape2d.Grid2D(shape2d.parse_shape2d(open(self.data_path).read()), cfg.dx, cfg.dy, 1.0, self.meta["align"])
         n = self.meta["steps_run"] if max_steps is None else max_steps
+        if cfg.in_fmt == "Shape3D":
+            class Frames:                       # Grid3D.cpp:303-336: a Shape3D run has cycle length frame_time and frame 0 throughout
+                num_frames = self.meta["frames"]
+                cycle_length = staticmethod(lambda: cfg.frame_time)
+                get_frame = staticmethod(lambda t: 0)
+            g2 = Frames
+        else:
+            g2 = shape2d.Grid2D(shape2d.parse_shape2d(open(self.data_path).read()), cfg.dx, cfg.dy, 1.0, self.meta["align"])
         return [(s, ce, ol) for s, (t, i, fr, ce, ol) in enumerate(shape2d.time_loop(g2, cfg, n), 1)]
 
     def step_dt(self):

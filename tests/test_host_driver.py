@@ -174,6 +174,38 @@ def test_driver_runs_the_shipped_example(driver, tmp_path):
 
 
 @pytest.mark.gpu
+def test_driver_result_file_equals_the_reference(driver, tmp_path, monkeypatch):
+    """f2 held to the REFERENCE, not to this library: fs3d_run (bit-exact kernels) on the shipped box_pipe case, all 100 steps; every
+    record of u, v, w, T in `_res.nc` equals the result layer the reference's own Solver3D::GetLayer handed to its NetCDF writer at
+    that step (tests/golden/ref_box_pipe_f32.npz: sha256 of all 10 layers, the first and the last one in full), and every printed
+    `err` equals the reference's print."""
+    from scipy.io import netcdf_file
+    import refgolden as RG
+    fx = RG.Fixture("box_pipe", "f32")
+    m = fx.meta
+    data = os.path.join(INPUTS, m["data"])
+    cfgf = tmp_path / "config.txt"
+    cfgf.write_text(m["config_text"])
+    prefix = str(tmp_path / "box")
+    monkeypatch.setenv("FS3D_DEFAULT_KERNEL", "4")
+    out = subprocess.run([driver, data, prefix, str(cfgf), "align", "GPU"], check=True, capture_output=True, text=True).stdout
+    assert "Sweep kernels:" in out and "part" not in out.split("Sweep kernels:")[1].splitlines()[0]
+    errs = re.findall(r"err = ([0-9.]+),", out)
+    assert errs == ["%.8f" % e for e in m["err_trace"]]
+    f = netcdf_file(prefix + "_res.nc", "r", mmap=False)
+    steps = m["layer_steps"]
+    assert f.variables["u"].shape[0] == len(steps) == 10
+    for r, st in enumerate(steps):
+        V = np.stack([f.variables[nm][r] for nm in "uvw"], axis=-1).astype(np.float32)
+        T = np.ascontiguousarray(f.variables["T"][r], np.float64)
+        assert RG.sha(V) == m["layer_sha"][str(st)]["outV"] and RG.sha(T) == m["layer_sha"][str(st)]["outT"], "record %d (step %d)" % (r, st)
+        if "outV_step%d" % st in fx.z:
+            np.testing.assert_array_equal(V, fx.z["outV_step%d" % st])
+            np.testing.assert_array_equal(T, fx.z["outT_step%d" % st])
+    f.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("mode", [["GPU"], ["GPU", "2", "--same-device"]])
 def test_driver_runs_a_multi_frame_input(driver, mode, tmp_path):
     """The 10-frame heart_us input: dt = cycle length / (frames * time_steps), the substep counter restarts at every frame

@@ -74,15 +74,20 @@ F32 = [c for c in RG.ALL if c[1] == "f32"]
 
 
 @pytest.mark.parametrize("name,prec", F32, ids=[c[0] for c in F32])
-def test_shape2d_loader_equals_the_reference(name, prec):
-    """Grid2D/Grid3D construction from the input files: dims, dt, FluidParams and every node (type, both BC kinds, boundary
-    values) equal what the reference's own Grid3D holds after LoadFromFile + Prepare(0)."""
+def test_grid_loaders_equal_the_reference(name, prec):
+    """Grid2D/Grid3D construction from the input files (Shape2D: extruded outline; Shape3D: rasterised triangle mesh): dims, dt,
+    FluidParams and every node (type, both BC kinds, boundary values) equal what the reference's own Grid3D holds after
+    LoadFromFile + Prepare(0)."""
     fx = RG.Fixture(name, prec)
     m = fx.meta
     nodes, cfg, dt = fx.loader()
     want = fx.nodes()
     assert nodes.shape == fx.dims and (nodes.dx, nodes.dy, nodes.dz) == (m["dx"], m["dy"], m["dz"])
-    assert dt == m["dt"] and cfg.grid2d.num_frames == m["frames"] and cfg.grid2d.cycle_length() == m["cycle_length"]
+    assert dt == m["dt"]
+    if cfg.in_fmt == "Shape2D":
+        assert cfg.grid2d.num_frames == m["frames"] and cfg.grid2d.cycle_length() == m["cycle_length"]
+    else:
+        assert cfg.frame_time == m["cycle_length"]
     assert nodes.count(grids.NODE_IN) == m["node_in"]
     assert np.array_equal(nodes.type, want.type)
     assert np.array_equal(nodes.bc_vel, want.bc_vel) and np.array_equal(nodes.bc_temp, want.bc_temp)
@@ -110,3 +115,15 @@ def test_multi_frame_geometry_equals_the_reference():
         assert np.array_equal(nodes.type, want_t), "node types at t = %g" % t
         vel = np.stack([np.asarray(getattr(nodes, k), np.float32) for k in ("vx", "vy", "vz")], axis=-1)
         assert np.array_equal(vel[want_t >= 2], fx.z["grid%d_bnd_vel" % i]), "wall velocities at t = %g" % t
+
+
+def test_shape3d_moving_mesh_equals_the_reference():
+    """Grid3D::Prepare_CPU(t) of the two-frame icosphere at times inside both frames and past the cycle: the interpolated mesh's
+    rasterisation (RasterPolygon / RasterLine / FloodFill, Grid3D.cpp:710-898), cell for cell."""
+    fx = RG.Fixture("sphere_3D", "f32")
+    m = fx.meta
+    assert m["frames"] == 2 and len(m["grid_times"]) == 5
+    for i, t in enumerate(m["grid_times"]):
+        nodes, cfg, dt = fx.loader(time=t)
+        assert np.array_equal(nodes.type, fx.z["grid%d_type" % i]), "node types at t = %g" % t
+        assert not fx.z["grid%d_bnd_vel" % i].any()                       # the reference leaves the mesh's wall velocities at zero

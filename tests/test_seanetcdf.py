@@ -130,3 +130,21 @@ def test_driver_runs_the_white_sea_input(driver, tmp_path, monkeypatch):
     f.close()
     u = first[0][..., 0]
     assert np.isfinite(u[u < 9e4]).all() and np.abs(u[u < 9e4]).max() > 0.01          # the inflow drives the basin
+
+
+def test_a_btree_node_that_names_itself_is_refused(driver, tmp_path):
+    """the chunk B-tree's level byte and child addresses come from the file.  A copy of the white_sea file whose TREE node
+    claims level 1 and lists ITSELF as its first child must be refused by both readers (it used to recurse until the stack ran out)."""
+    raw = bytearray(open(DATA, "rb").read())
+    p = raw.find(b"TREE")
+    assert p > 0 and raw[p + 4] == 1 and raw[p + 5] == 0
+    rank = 2
+    ks = 8 + 8 * (rank + 1)
+    raw[p + 5] = 1                                                   # "internal node"
+    raw[p + 24 + ks:p + 24 + ks + 8] = int(p).to_bytes(8, "little")  # first child = this node (file base address is 0)
+    bad = tmp_path / "self.nc"
+    bad.write_bytes(bytes(raw))
+    with pytest.raises(hdf5_min.Hdf5Error):
+        hdf5_min.Hdf5File(str(bad)).read("z")
+    r = subprocess.run([driver, str(bad), str(tmp_path / "out"), CONF, "--grid-only", str(tmp_path / "g.bin")], capture_output=True, text=True)
+    assert r.returncode not in (0, -11, 139) and "HDF5" in (r.stderr + r.stdout), (r.returncode, r.stderr[-300:])

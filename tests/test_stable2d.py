@@ -1,8 +1,9 @@
 """The reference's 2D path as CPU plumbing (BASELINE configs[0]: a 128 x 128 lid-driven cavity through the
 Stable solver -- explicit advection/diffusion + the Gauss-Seidel pressure projection, the reference's only Poisson solve).
-Parity unpinned (the reference's 2D sources do not compile here without stand-ins, no shipped 2D config parses): the C++ solver
-(host/Stable2D.h through fs2d_run) against its Python twin (stable2d.py) bit for bit on a 54 x 54 cavity, and properties of the
-authored 128 x 128 case (tests/golden/inputs/cavity_2D_*: a passive U-shaped wall and a lid moving at 1 m/s, Re 100)."""
+Pinned to the reference (r3): tests/golden/ref2d_*.npz hold fields of the reference's own Grid2D + StableSolver2D objects (built as
+they lie, oracle/ref_harness_2d.cpp) on the authored cavity at 54 x 54 and 128 x 128 and on the 10-frame heart_us outline with moving
+walls; the C++ solver (host/Stable2D.h through fs2d_run) and its Python twin (stable2d.py) equal them bit for bit (last tests of
+this file).  Also: C++ against the twin, and properties of the authored 128 x 128 case."""
 import os
 import re
 import subprocess
@@ -82,3 +83,50 @@ def test_cavity_128(driver2d, tmp_path):
     div[1:-1, 1:-1] = (u[2:, 1:-1] - u[:-2, 1:-1]) / (2 * cfg.dx) + (v[1:-1, 2:] - v[1:-1, :-2]) / (2 * cfg.dy)
     core = inn.copy(); core[:, jl - 3:] = False
     assert np.abs(div[core]).max() < 0.5 and np.abs(T[inn] - 1.0).max() == 0
+
+
+# ---- held to the REFERENCE: tests/golden/ref2d_*.npz are outputs of the reference's own Grid2D + StableSolver2D objects
+# (oracle/ref_harness_2d.cpp over the reference's translation units compiled where they lie; tests/golden/make_ref_golden.py)
+def _fx2d(name):
+    import json
+    z = np.load(os.path.join(os.path.dirname(INP), "ref2d_%s.npz" % name))
+    return z, json.loads(str(z["meta"]))
+
+
+@pytest.mark.parametrize("name,upto", [("cavity54", 3), ("heart2d", 1)])
+def test_python_solver_equals_the_reference(name, upto, tmp_path):
+    """Grid2D (every step's node types: moving walls in heart2d) and the Stable solver's U, V, T after every dumped step, bit for bit
+    (the Python twin is slow: the 128 x 128 cavity and the later heart2d steps are held by the C++ solver below)."""
+    z, m = _fx2d(name)
+    m["steps"] = [s_ for s_ in m["steps"] if s_ <= upto]
+    cfgp = str(tmp_path / "c.txt")
+    open(cfgp, "w").write(m["config_text"])
+    cfg = shape2d.Config(cfgp)
+    g = shape2d.Grid2D(shape2d.parse_shape2d(open(os.path.join(INP, m["data"])).read()), cfg.dx, cfg.dy, cfg.baseT, False)
+    assert (g.dimx, g.dimy) == tuple(m["dims"]) and g.num_frames == m["frames"] and g.cycle_length() == m["cycle_length"]
+    s = stable2d.Stable2D(g, np.float32(cfg.viscosity / cfg.density))
+    assert float(np.float32(cfg.viscosity / cfg.density)) == m["v_vis"]
+    dt = g.cycle_length() / (g.num_frames * cfg.time_steps)
+    assert dt == m["dt"]
+    t = dt
+    for step in range(1, max(m["steps"]) + 1):
+        g.prepare(t); s.update_boundaries(); s.time_step(dt, cfg.num_global, cfg.num_local); t += dt
+        assert "%.4f" % s.err == "%.4f" % m["err_trace"][step - 1]
+        if step in m["steps"]:
+            assert np.array_equal(g.cell, z["type_step%d" % step]), "node types at step %d" % step
+            for a, v in zip(s.next, "UVT"):
+                assert np.array_equal(a, z["%s_step%d" % (v, step)]), "%s after step %d" % (v, step)
+
+
+@pytest.mark.parametrize("name", ["cavity54", "cavity128", "heart2d"])
+def test_cpp_solver_equals_the_reference(driver2d, name, tmp_path):
+    """host/Stable2D.h through fs2d_run: the last layer's U, V, T and the printed err values equal the reference's."""
+    z, m = _fx2d(name)
+    cfgp, out, dump = str(tmp_path / "c.txt"), str(tmp_path / "o.cdl"), str(tmp_path / "o.bin")
+    open(cfgp, "w").write(m["config_text"])
+    n = max(m["steps"])
+    r = subprocess.run([driver2d, os.path.join(INP, m["data"]), out, cfgp, "--steps", str(n), "--dump", dump], check=True, capture_output=True, text=True, timeout=900).stdout
+    assert "%i,%i,1" % tuple(m["dims"]) in r and "dt = %f" % m["dt"] in r
+    assert re.findall(r"err = ([0-9.]+),", r) == ["%.4f" % e for e in m["err_trace"][:n]]
+    for a, v in zip(_dump(dump), "UVT"):
+        assert np.array_equal(a, z["%s_step%d" % (v, n)]), v
