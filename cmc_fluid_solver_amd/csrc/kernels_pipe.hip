@@ -148,14 +148,22 @@ typedef __amdgpu_buffer_rsrc_t rsrc_t;
 // Raw buffer access: address = descriptor base (4 SGPRs) + soffset (1 SGPR, wave-uniform row) +
 // voffset (1 VGPR, per-lane byte offset).  One SGPR per row instead of a 64-bit pointer, no 64-bit
 // VALU address arithmetic, and a store is masked by an out-of-range voffset instead of a branch.
+// Cache policy (aux operand: 2 = nt): `cur` is read once per sweep, `next` / `temp_out` are written once and read by the next launch
+// only (see kernels_part.hip); the temp loads stay cached (neighbour rows, second read of the O phase).  Hints only: same bits.
+#ifndef PIPE_AUX_CUR
+#define PIPE_AUX_CUR 2
+#endif
+#ifndef PIPE_AUX_ST
+#define PIPE_AUX_ST 2
+#endif
 template <typename R> struct Buf;
 template <> struct Buf<float> {
-    static __device__ __forceinline__ float ld(rsrc_t r, unsigned vo, unsigned so) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, vo, so, 0)); }
-    static __device__ __forceinline__ void st(rsrc_t r, unsigned vo, unsigned so, float v) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, vo, so, 0); }
+    template <int AUX = 0> static __device__ __forceinline__ float ld(rsrc_t r, unsigned vo, unsigned so) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, vo, so, AUX)); }
+    template <int AUX = 0> static __device__ __forceinline__ void st(rsrc_t r, unsigned vo, unsigned so, float v) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, vo, so, AUX); }
 };
 template <> struct Buf<double> {
-    static __device__ __forceinline__ double ld(rsrc_t r, unsigned vo, unsigned so) { return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, vo, so, 0)); }
-    static __device__ __forceinline__ void st(rsrc_t r, unsigned vo, unsigned so, double v) { __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, vo, so, 0); }
+    template <int AUX = 0> static __device__ __forceinline__ double ld(rsrc_t r, unsigned vo, unsigned so) { return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, vo, so, AUX)); }
+    template <int AUX = 0> static __device__ __forceinline__ void st(rsrc_t r, unsigned vo, unsigned so, double v) { __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, vo, so, AUX); }
 };
 #define BUF_OOB 0xFFFFFFFFu      // voffset >= num_records: the hardware drops the store
 
@@ -228,7 +236,8 @@ struct Chunk {
     // Cells past the end of the line and lanes past the lane axis receive clamped (valid, meaningless) data.
     // EDGES (Z only): also fetch the lines just below/above the tile (-> tile rows 64 and 65 in land()).
     // HALO: also the two cells just outside [c0, c0+PC) on the own line (clamped into the line).
-    template <bool EDGES, bool HALO>
+    // AUX: cache policy of the loads (PIPE_AUX_CUR for the read-once `cur` fields)
+    template <bool EDGES, bool HALO, int AUX = 0>
     __device__ __forceinline__ void issue(rsrc_t f, int dub, int c0, Raw &r) const
     {
         if (DIR == 2) {
@@ -239,7 +248,7 @@ struct Chunk {
             for (int i = 0; i < PR; i++) {
                 int row = i * RPI + rsub;
                 row = row > rows_valid - 1 ? rows_valid - 1 : row;
-                r.q[i] = __builtin_amdgcn_raw_buffer_load_b128(f, (unsigned)(row * dimz + pos) * (unsigned)sizeof(R), row0 + dub, 0);
+                r.q[i] = __builtin_amdgcn_raw_buffer_load_b128(f, (unsigned)(row * dimz + pos) * (unsigned)sizeof(R), row0 + dub, AUX);
             }
             if (EDGES) {
                 // lanes [0,PR): the line below the tile (row -1); lanes [PR,2PR): the line above (row rows_valid)
@@ -249,7 +258,7 @@ struct Chunk {
             }
         } else {
 #pragma unroll
-            for (int t = 0; t < PC; t++) r.v[t] = Buf<R>::ld(f, vob, soff_halo(c0, t) + dub);   // cell n of a slab may be a neighbour's ghost plane
+            for (int t = 0; t < PC; t++) r.v[t] = Buf<R>::template ld<AUX>(f, vob, soff_halo(c0, t) + dub);   // cell n of a slab may be a neighbour's ghost plane
         }
         if (HALO) {
             r.lo = Buf<R>::ld(f, vob, soff_halo(c0, -1) + dub);
@@ -328,13 +337,13 @@ struct Chunk {
                 const int row = r * RPS + rsub;
                 const R val = trow[r * RPS * TSTRIDE];
                 const bool ok = col_ok && row < rows_valid && ((tmask >> r) & 1u);
-                Buf<R>::st(f, ok ? (unsigned)(row * dimz + base(c0) + col) * (unsigned)sizeof(R) : BUF_OOB, row0 + fo, val);
+                Buf<R>::template st<PIPE_AUX_ST>(f, ok ? (unsigned)(row * dimz + base(c0) + col) * (unsigned)sizeof(R) : BUF_OOB, row0 + fo, val);
             }
         } else {
 #pragma unroll
             for (int t = 0; t < PC; t++) {
                 const bool ok = lane_valid && cell_ok(c0 + t) && ((wmask >> t) & 1u);
-                Buf<R>::st(f, ok ? vob : BUF_OOB, soff(c0 + t) + fo, in[t]);
+                Buf<R>::template st<PIPE_AUX_ST>(f, ok ? vob : BUF_OOB, soff(c0 + t) + fo, in[t]);
             }
         }
     }
@@ -346,7 +355,7 @@ struct Chunk {
         else {
             const unsigned vo = live_only ? vob_live : vob_st;
 #pragma unroll
-            for (int t = 0; t < PC; t++) Buf<R>::st(f, vo, soff(c0 + t) + fo, in[t]);
+            for (int t = 0; t < PC; t++) Buf<R>::template st<PIPE_AUX_ST>(f, vo, soff(c0 + t) + fo, in[t]);
         }
     }
     // central difference along the sweep, in place: a[t] <- (a[t+1] - a[t-1]) / two_ds   (TimeLayer3D.h:338-340)
@@ -650,7 +659,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_sweep_pipe(SweepParams<R> p, int
             SB;
             // I6: temperature (cur layer)
             Raw rCT;
-            ck.template issue<false, false>(Lcur, (int)(3 * fsb), c0, rCT);
+            ck.template issue<false, false, PIPE_AUX_CUR>(Lcur, (int)(3 * fsb), c0, rCT);
             SB;
             // C5: temperature gradient along s (momentum RHS, AdiSolver3D.cpp:766/781/796)
             R gT[PC];
@@ -661,7 +670,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_sweep_pipe(SweepParams<R> p, int
             SB;
             // I7..I9 / C6..C9: the four `cur` fields -> right-hand sides
             Raw rC0, rC1, rC2;
-            ck.template issue<false, false>(Lcur, 0, c0, rC0);
+            ck.template issue<false, false, PIPE_AUX_CUR>(Lcur, 0, c0, rC0);
             SB;
             {
                 R cT[PC];
@@ -670,7 +679,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_sweep_pipe(SweepParams<R> p, int
                 for (int t = 0; t < PC; t++) { myD[(c0 + t) * 64] = divc<FM>(cT[t] * R(3), dDt, ok) + acc[t]; if (FM && (t & 3) == 3) SB; }   // T right-hand side -> LDS
             }
             SB;
-            ck.template issue<false, false>(Lcur, (int)fsb, c0, rC1);
+            ck.template issue<false, false, PIPE_AUX_CUR>(Lcur, (int)fsb, c0, rC1);
             SB;
             {
                 R cV[PC];
@@ -679,7 +688,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_sweep_pipe(SweepParams<R> p, int
                 for (int t = 0; t < PC; t++) { R d = divc<FM>(cV[t] * R(3), dDt, ok); if (DIR == 0) d = d - gT[t]; st1[c0 + t] = d; if (FM && (t & 3) == 3) SB; }
             }
             SB;
-            ck.template issue<false, false>(Lcur, (int)(2 * fsb), c0, rC2);
+            ck.template issue<false, false, PIPE_AUX_CUR>(Lcur, (int)(2 * fsb), c0, rC2);
             SB;
             {
                 R cV[PC];

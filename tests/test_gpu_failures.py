@@ -23,7 +23,12 @@ def test_lost_relay_handover_is_an_error(built, monkeypatch):
         s.sweep(1, 0.1, capi.LAYER_CUR, capi.LAYER_TEMP, capi.LAYER_NEXT, merge=True)
     assert ei.value.status == capi.ERR_HIP and "hand-over" in str(ei.value)
     monkeypatch.delenv("FS3D_TEST_DROP_HANDOFF")
-    s.sweep(1, 0.1, capi.LAYER_CUR, capi.LAYER_TEMP, capi.LAYER_NEXT, merge=True)      # the context is usable again
+    with pytest.raises(capi.Fs3dError):                  # the hook is read ONCE, at fs3d_create: this context keeps dropping
+        s.sweep(1, 0.1, capi.LAYER_CUR, capi.LAYER_TEMP, capi.LAYER_NEXT, merge=True)
+    s.close()
+    s = capi.Solver(g, capi.fluid_params(np.float32, *PARAMS), np.float32)              # a context created without it is clean
+    s.set_option(capi.OPT_SWEEP_KERNEL, capi.SWEEP_PIPE)
+    s.sweep(1, 0.1, capi.LAYER_CUR, capi.LAYER_TEMP, capi.LAYER_NEXT, merge=True)
     s.close()
 
 

@@ -65,7 +65,11 @@ def test_exact_kernels_equal_the_reference(built, name, prec):
 # after 3 steps; the partition kernels sit CLOSER to that fp64 solution than the fp32 reference does: tests/test_gpu_part.py).
 # The bit-exact kernels (test above) meet the reference exactly at every size; these bounds are 1.5 x the measured distances.
 TOL = {"u_bend": (1e-6, 1e-6), "box_pipe": (1e-6, 1e-6), "non_uniform_pipe": (1e-6, 1e-6), "heart_us": (1e-6, 1e-6),
-       "box128": (3.4e-6, 1.1e-6), "box256": (6.4e-6, 3.5e-6), "non_uniform256": (4.8e-6, 2.1e-6)}
+       "box128": (3.4e-6, 1.1e-6), "box256": (6.4e-6, 3.5e-6), "non_uniform256": (4.8e-6, 2.1e-6),
+       # Shape3D bodies are closed (no inflow): the only motion is the weak flow the T = 0 skin drives against T = 1 inside -- a stiff
+       # boundary layer ("where the tolerance stops holding"); measured box_pipe_3D (128^3, 10 steps) 3.0e-6 / 8.0e-7,
+       # tetra 1.8e-7 / 1.4e-7, sphere_3D (7 steps) 1.1e-6 / 3.5e-6
+       "box_pipe_3D": (4.5e-6, 1.2e-6), "tetra": (1e-6, 1e-6), "sphere_3D": (1.8e-6, 5.3e-6)}
 F32 = [c[0] for c in RG.ALL if c[1] == "f32"]
 
 
