@@ -12,8 +12,10 @@
 //     BC_NOSLIP for both, v = 0, T = 0 (Init's values).
 //   * cells addressed outside the grid (the reference writes past its array) are ignored; a scan line that would never reach its
 //     end cell (the reference loops until the int wraps) throws.
-// Parity unpinned: the only shipped Shape3D case (large_tests/heart_us) carries a config the reference's parser rejects, and the
-// reference cannot be built here.  Python twin: cmc_fluid_solver_amd/shape3d.py (same operations; tests compare the two).
+// Pinned to the reference (r3) through the Python twin cmc_fluid_solver_amd/shape3d.py (same operations; tests/test_shape3d.py compares
+// the two cell for cell): the twin equals the node arrays of the reference's own Grid3D on the shipped box_pipe_3D and tetra meshes and
+// on a two-frame icosphere at five times (tests/test_ref_golden.py, tests/golden/ref_box_pipe_3D_f32.npz ...); the zero-filled reading
+// of the NODE_BOUND cells is what the reference's run holds there.
 #pragma once
 #include <algorithm>
 #include <cmath>

@@ -10,8 +10,10 @@
 //     does not enter err; q_new = 0 with q != 0 gives inf and keeps the sweep going;
 //   * "Exceeded max number of iterations" / "Error is too big!" throw instead of exit(1);
 //   * bc_type NoSlip only (the free-slip rasteriser variant, Grid2D.cpp:117-153 with bc_strength, is not restated).
-// Parity unpinned: the 2D translation units do not compile here without stand-ins (mpi.h, cuda_runtime.h through Common/IO.h) and no
-// shipped 2D config parses with the current Config (they use the old keys).  Python twin: cmc_fluid_solver_amd/stable2d.py.
+// Pinned to the reference (r3): tests/test_stable2d.py holds this solver (through fs2d_run) bit for bit to U, V, T and the err prints of
+// the reference's own Grid2D + StableSolver2D objects (oracle/ref_harness_2d.cpp over the reference's translation units as they lie) on
+// the authored cavity at 54^2 and 128^2 and on the 10-frame heart outline with moving walls (tests/golden/ref2d_*.npz) -- the three
+// readings above are what the reference's Linux build does.  Python twin: cmc_fluid_solver_amd/stable2d.py.
 #pragma once
 #include <cmath>
 #include <stdexcept>

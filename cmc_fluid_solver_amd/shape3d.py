@@ -6,8 +6,9 @@ BC_NOSLIP, v = 0, T = 0 -- and cells addressed outside the grid are ignored).  R
   Grid3D::Load3DShape / Init / Prepare3D_Shape / ComputeSubframeInfo / Build / RasterPolygon / ProjectPointOnPolygon /
   RasterLine / FloodFill                         (FluidSolver3D/Grid3D.cpp:351-431, 676-946)
   BBox3D::Build                                  (Common/Geometry.h:510-529)
-Parity unpinned (no reference output exists for a Shape3D input here); tests compare this twin with the C++ loader and with
-hand-derived properties of small meshes.
+Pinned to the reference (r3): tests/test_ref_golden.py holds this loader cell for cell to the node arrays of the reference's own
+Grid3D on the shipped box_pipe_3D and tetra meshes and on a two-frame icosphere at five times (tests/golden/ref_*_3D_*.npz,
+ref_tetra_f32.npz); tests/test_shape3d.py compares the C++ loader with this twin.
 """
 import math
 

@@ -1,7 +1,8 @@
 """The reference's 2D path (CPU only): explicit advection/diffusion step + pressure projection over a Grid2D.
 
 Python twin of cmc_fluid_solver_amd/host/Stable2D.h (same operations in np.float32 / double; the header lists the reference lines --
-StableSolver2D.cpp:21-234, TimeLayer2D.h:24-186, Solver2D.cpp:21-84 -- and the three deliberate readings).  Parity unpinned.
+StableSolver2D.cpp:21-234, TimeLayer2D.h:24-186, Solver2D.cpp:21-84 -- and the three deliberate readings).  Pinned to the reference (r3): equal to the reference's own StableSolver2D + Grid2D bit for bit
+on the fixtures tests/golden/ref2d_*.npz (tests/test_stable2d.py).
 Plain Python loops for the Gauss-Seidel sweeps (they are sequential by definition): small grids only.
 """
 import numpy as np

@@ -6,19 +6,17 @@
  * float (the reference's FTYPE, Geometry.h:21) and double (the reference's
  * one-line FTYPE patch).  See fs3d_oracle_body.inc for per-function citations.
  *
- * PARITY PINNING STATUS (see DESIGN.md "Oracle"): the reference's own CPU path
- * cannot be built in this image without stand-ins for cuda_runtime.h / libnetcdf
- * (every FluidSolver3D translation unit includes them), and the reference ships
- * no tests or golden outputs.  What IS pinned:
+ * PARITY PINNING STATUS: PINNED to the reference itself.  The reference's whole CPU path builds in this
+ * image as it lies (oracle/Makefile target ref_full: genuine cuda_runtime.h from the triton package, no stand-ins); this oracle
+ * equals its fields, err prints, EvalDivError values and GetLayer outputs BIT FOR BIT on the fixtures of tests/golden/ref_*.npz
+ * (tests/test_ref_golden.py; fp32 as shipped and fp64 with FTYPE switched; 64^3 x 100 steps ... 256^3).  Also pinned piecewise:
  *   - SolveTridiagonal and FluidParams/AlignBy32 are checked bit-for-bit against
  *     the reference's own headers compiled as they lie (oracle/_ref, built by
  *     oracle/Makefile from /root/reference/src/Common/{Algorithms,Geometry}.h);
  *   - the Shape2D grid loader + stepper are checked against the reference outputs
  *     recorded in SURVEY.md section 8c/8d (grid dims, NODE_IN counts, err range of
  *     the 64^3 box_pipe example).
- * Field-level golden vectors of the reference binary do not exist:
- * for the matrix build / stencil / merge / div-error functions parity is UNPINNED
- * beyond those scalar outputs.
+ * (Rounds 1-2 had no field-level vectors of the reference binary; tests/golden/ref_*.npz are those vectors.)
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
  * this library.  The product path (libfs3d_hip.so) never links or calls it.

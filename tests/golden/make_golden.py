@@ -4,9 +4,8 @@
 WHAT THESE FIXTURES ARE: outputs of the CPU oracle (oracle/fs3d_oracle.c, the restatement of the
 reference's CPU path) on small deterministic inputs -- regression pins of the restatement and the
 vectors the GPU parity tests and the golden tests replay.  They are NOT outputs of the reference
-binary: the reference's FluidSolver3D translation units cannot be compiled in this image without
-stand-ins for cuda_runtime.h / libnetcdf ("Oracle"), and the reference ships no golden
-data of its own.  What is pinned to the reference itself is listed in tests/test_oracle_pins.py.
+binary (those are tests/golden/ref_*.npz, made by make_ref_golden.py): small synthetic boxes that exist in no input file,
+kept as unit-level regression pins of the restatement.
 
 Run from the repo root:  python tests/golden/make_golden.py
 """

@@ -6,9 +6,9 @@ Common/Geometry.h compiled as they lie, see oracle/Makefile):
   - FluidParams (both constructors) and AlignBy32.
 PINNED TO REFERENCE OUTPUTS RECORDED IN SURVEY.md (the reference binary run by the survey):
   - see tests/test_grid_loader.py (grid dims, NODE_IN counts, err range of the shipped 64^3 example).
-SELF-CONSISTENCY ONLY (parity UNPINNED against the reference binary -- it cannot be built in this image
-without stand-ins and ships no golden data): BuildMatrix/DissFunc/merge/EvalDivError are checked
-against hand-computed cases, algebraic properties and the committed golden vectors of the restatement.
+PINNED TO THE REFERENCE'S WHOLE CPU PATH since round 3: tests/test_ref_golden.py holds the oracle bit for bit to fixtures produced
+by the reference's own translation units (oracle/Makefile target ref_full).  The hand-computed cases, algebraic properties and the
+self-generated golden vectors of BuildMatrix/DissFunc/merge/EvalDivError below remain as unit-level checks of the restatement.
 """
 import ctypes as C
 import os

@@ -1,7 +1,7 @@
 """Shape3D input surface (second loader): triangle meshes rasterised into the Node array.
-Parity unpinned (no reference output for a Shape3D input exists here): the C++ loader (host/Shape3D.h, through fs3d_run
---grid-only) is compared with its Python twin (shape3d.py) cell for cell, and both with hand-derived properties of small
-closed meshes written by the test."""
+The C++ loader (host/Shape3D.h, through fs3d_run --grid-only) is compared with its Python twin (shape3d.py) cell for cell, and both
+with hand-derived properties of small closed meshes written by the test; the twin itself is held to the reference's own Grid3D in
+tests/test_ref_golden.py (shipped box_pipe_3D / tetra meshes, this file's two-frame icosphere)."""
 import os
 import re
 import subprocess
