@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(LT * NCH, WPS) k_sweep_part(SweepParams<R> p, 
 {
     static_assert(DIR == 0 || DIR == 1, "lanes along k: X and Y sweeps");
     extern __shared__ __attribute__((aligned(16))) unsigned char part_smem[];
-    static_assert(LT == 32 || LT == 64, "lines per workgroup");
+    static_assert(LT == 16 || LT == 32 || LT == 64, "lines per workgroup");
     R *const ldsD = (R *)part_smem;                      // [NCH*M][LT]  dT of every cell (P -> E)
     R *const ex = ldsD + NCH * M * LT;                  // [PART_EXW][NCH][LT]
     const int t = threadIdx.x, kk = t % LT, ch = t / LT;
@@ -649,9 +649,9 @@ static bool part_launch_xy(fs3d_ctx *c, const SweepParams<R> &p)
     // solve and store at the same time (tools/ab_tiles.py, interleaved on one box: 64 lines 6.12 ms per step, 32 lines 5.81,
     // 32 lines with the late start 5.63-5.66).  Few workgroups (thin slabs) and 512-cell lines: lane tiles fastest.
     // (the late start only where it was measured: 512-thread workgroups, two per CU, at least two generations of them)
-    const bool late = LT == 32 && NCH == 16 && M == 16 && (long long)n_o * n_tiles >= 1024;
+    const bool late = LT <= 32 && NCH == 16 && M == 16 && (long long)n_o * n_tiles >= 1024;
     static const int late_slab = part_exp_env("FS3D_PART_LATE_SLAB", 0);   // experiment: slab kernels (XB != 0), delay units
-    int order = order_env >= 0 ? order_env : (LT == 32 ? (((long long)n_o * n_tiles < 1024 || NCH == 32) ? 1 : 0) | (late ? 0x40 | (4 << 8) : 0) : 0);
+    int order = order_env >= 0 ? order_env : (LT <= 32 ? (((long long)n_o * n_tiles < 1024 || NCH == 32) ? 1 : 0) | (late ? 0x40 | (4 << 8) : 0) : 0);
     if (XB != 0 && late_slab > 0 && LT * NCH <= 512 && (long long)n_o * n_tiles >= 512) order |= 0x40 | (late_slab << 8);
     hipLaunchKernelGGL((k_sweep_part<R, DIR, M, NCH, WPS, LT, PF, XB, OPF, KT>), dim3((unsigned)(n_o * n_tiles)), dim3(LT * NCH), lds, c->stream, p, n_o, n_tiles, order);
     return true;
@@ -663,7 +663,7 @@ static bool part_dispatch_xy(fs3d_ctx *c, const SweepParams<R> &p)
     const int n = DIR == 0 ? p.dimx : p.dimy;
     if (n < 4) return false;
     if constexpr (std::is_same<R, float>::value) {       // fp64 contexts run the exact kernels
-        static const int variant = getenv("FS3D_PART_VARIANT") ? atoi(getenv("FS3D_PART_VARIANT")) : 0;   // other tilings of the same arithmetic (result-neutral: tested)
+        static const int variant = getenv("FS3D_PART_VARIANT") ? atoi(getenv("FS3D_PART_VARIANT")) : 0;   // 16 / 32 / 64 lines per workgroup: same chunks, same arithmetic, same bits (tested)
         if (DIR == 0 && p.xiface_pass) {
             // first pass of the cross-slab sweep: the slab's interface words (whole chunks only)
             constexpr int D0 = 0;
@@ -689,14 +689,23 @@ static bool part_dispatch_xy(fs3d_ctx *c, const SweepParams<R> &p)
         if (n <= 64) return part_launch_xy<R, DIR, 16, 4, 4, 32>(c, p);
         if (n <= 128) return part_launch_xy<R, DIR, 16, 8, 4, 32>(c, p);
         if (n <= 256) {
-            // measured alternatives (profiles/r2_variants.txt), kept for re-measurement on other boxes:
+#ifdef FS3D_EXPERIMENTS
+            // measured alternatives (profiles/r2_variants.txt): other chunk sizes = another rounding of the same algebra, so they
+            // exist in experiment builds only
             if (variant == 1) return part_launch_xy<R, DIR, 32, 8, 2, 32>(c, p);     // 256 threads x 32 cells, <= 256 VGPRs: 1.15x slower
             if (variant == 10) return part_launch_xy<R, DIR, 8, 32, 4, 32, 2, false, 2, true>(c, p);   // 8 cells per thread, 32 lines, the temp values
                                                                                                     // stay in registers for the merge: 1.1x slower
                                                                                                     // (without keeping them: 1.25x)
+#endif
             // 64 lines x 16 chunks (one workgroup of 1024 threads per CU, 256-byte row pieces) was the default until the layer fields
             // were padded; since then two 32-line workgroups per CU are faster (their phases overlap inside the CU)
             if (variant == 64) return part_launch_xy<R, DIR, 16, 16, 4, 64>(c, p);
+            if (variant == 32) return part_launch_xy<R, DIR, 16, 16, 4, 32>(c, p);
+            // (r3) with the nontemporal streams the X sweep -- rows a plane apart -- is faster again with 256-byte row pieces
+            // (64-line tiles: 0.2685 -> 0.2514 ms), the Y sweep stays with two 32-line workgroups per CU (0.2427 vs 0.2482):
+            // profiles/r3_ab_env.txt.  Few workgroups (small planes): 32-line tiles, twice as many.
+            if (DIR == 0 && variant == 0 && (long long)p.dimy * ((p.dimz + 63) / 64) >= 512) return part_launch_xy<R, DIR, 16, 16, 4, 64>(c, p);
+            if (variant == 16) return part_launch_xy<R, DIR, 16, 16, 4, 16>(c, p);      // 16-line tiles: 256 threads, four workgroups per CU, 64-byte row pieces
             return part_launch_xy<R, DIR, 16, 16, 4, 32>(c, p);
         }
         if (n <= 512) return part_launch_xy<R, DIR, 16, 32, 4, 32>(c, p);
@@ -1094,7 +1103,7 @@ static bool part_launch_z(fs3d_ctx *c, const SweepParams<float> &p)
     const int npl = p.o_count ? p.o_count : p.dimx;
     // 8 rows per wave where the grid is large enough to give every CU several workgroups that way; fewer on small grids /
     // thin slabs (a 64^3 grid would otherwise launch 32 workgroups for 256 CUs)
-    int LG = lg_env > 0 ? lg_env : 8;
+    int LG = lg_env > 0 ? lg_env : 16;                   // (r3) 16 rows per wave: 0.219 -> 0.207 ms at 256^3 (profiles/r3_ab_env.txt)
     while (LG > 1 && (long long)((rows + LG - 1) / LG) * npl < 4096) LG >>= 1;
     if (LG > rows) LG = rows;
     const int n_grp = (rows + LG - 1) / LG;

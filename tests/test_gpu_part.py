@@ -516,8 +516,11 @@ def test_halo_planes_beside_the_interior_sweep(built, nranks):
 
 
 def test_results_do_not_depend_on_layout_padding_or_workgroup_schedule(built, tmp_path):
-    """Field padding / layer skew (fs3d_create) and the workgroup order / late start of the X/Y kernels are speed knobs: the fields
-    after two steps are bit-identical whatever they are set to (each setting in a process of its own: the knobs are read once)."""
+    """Every FS3D_* environment variable the production library reads is a speed knob: field padding / layer skew (fs3d_create) and
+    the tiling of the X/Y kernels (FS3D_PART_VARIANT) -- the fields after two steps are bit-identical whatever they are set to (each
+    setting in a process of its own: the knobs are read once).  The kernel-experiment knobs (FS3D_PART_ORDER -- whose bits 1/2 skip
+    loads and give WRONG numbers --, _LDSPAD, _LATE_SLAB, _ZLG) exist only in -DFS3D_EXPERIMENTS builds (build.build_variant):
+    libfs3d_hip.so must not read them at all."""
     import subprocess
     import sys
     code = ("import sys, hashlib, numpy as np\n"
@@ -531,8 +534,9 @@ def test_results_do_not_depend_on_layout_padding_or_workgroup_schedule(built, tm
             "print('HASH', h.hexdigest(), s.last_sweep_kernels())\n")
     outs = {}
     for tag, env in (("default", {}), ("no padding", {"FS3D_FIELD_PAD": "0", "FS3D_LAYER_SKEW": "0"}), ("big padding", {"FS3D_FIELD_PAD": "4164", "FS3D_LAYER_SKEW": "66048"}),
-                     ("rows fastest, no late start", {"FS3D_PART_ORDER": "0"}), ("tiles fastest, late start", {"FS3D_PART_ORDER": str(1 | 0x40 | (3 << 8))}),
-                     ("64-line tiles", {"FS3D_PART_VARIANT": "64"})):
+                     ("experiment knobs are not read by the product", {"FS3D_PART_ORDER": "6", "FS3D_PART_LDSPAD": "8192", "FS3D_PART_LATE_SLAB": "3", "FS3D_PART_ZLG": "2"}),
+                     ("64-line tiles", {"FS3D_PART_VARIANT": "64"}), ("32-line tiles", {"FS3D_PART_VARIANT": "32"}), ("16-line tiles", {"FS3D_PART_VARIANT": "16"}),
+                     ("other chunk sizes exist in experiment builds only", {"FS3D_PART_VARIANT": "10"})):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300,
                            cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("HASH")]
