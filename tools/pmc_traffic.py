@@ -11,7 +11,7 @@ def load(path, name):
             agg[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
     return agg
 f = load(sys.argv[1], "FETCH_SIZE"); w = load(sys.argv[2], "WRITE_SIZE")
-cells = float(sys.argv[3]) if len(sys.argv) > 3 else 256.0**3
+cells = float(sys.argv[3]) if len(sys.argv) > 3 and not sys.argv[3].startswith("--") else 256.0**3
 print("%-52s %6s %14s %14s %12s %12s" % ("kernel", "calls", "fetch KiB/launch", "write KiB/launch", "B/cell raw", "B/cell corr"))
 for k in sorted(f):
     fk = sum(f[k]) / len(f[k]); wk = sum(w.get(k, [0])) / max(1, len(w.get(k, [0])))
