@@ -51,12 +51,13 @@ def build(force=False, verbose=False):
     return LIB
 
 
-def build_variant(name, extra_flags, source="kernels_part.hip"):
-    """Kernel experiments: libfs3d_hip_<name>.so with `source` compiled with extra flags (load it with FS3D_LIB_PATH)."""
+def build_variant(name, extra_flags, source="kernels_part.hip", experiments=True):
+    """Kernel experiments: libfs3d_hip_<name>.so with `source` compiled with extra flags (load it with FS3D_LIB_PATH).
+    experiments: -DFS3D_EXPERIMENTS (the timing-experiment environment knobs exist only in such builds)."""
     build()
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     obj = os.path.join(CSRC, source.replace(".hip", "_var_%s.o" % name))
-    subprocess.check_call([hipcc] + FLAGS_BY_SOURCE.get(source, FLAGS) + ["-DFS3D_EXPERIMENTS"] + list(extra_flags) + ["-c", os.path.join(CSRC, source), "-o", obj])
+    subprocess.check_call([hipcc] + FLAGS_BY_SOURCE.get(source, FLAGS) + (["-DFS3D_EXPERIMENTS"] if experiments else []) + list(extra_flags) + ["-c", os.path.join(CSRC, source), "-o", obj])
     objs = [obj if s == source else os.path.join(CSRC, s.replace(".hip", ".o")) for s in SOURCES]
     lib = os.path.join(HERE, "libfs3d_hip_%s.so" % name)
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"])

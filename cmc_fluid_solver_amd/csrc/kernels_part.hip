@@ -158,15 +158,9 @@ __device__ __forceinline__ void part_step(R lead, R diag, R trail, R &cp, R &sp,
 #endif
 #define PART_EXW 18               // interface words per (line, chunk): 5 per matrix, 2 per right-hand side
 
-// YF ("y form", r3): launches whose `next` nobody reads (all local iterations but the last) only store the merged temp
-// y = (x + temp) / 2.  Substituting x = 2y - temp into the rows gives the SAME matrix with the right-hand side (d + A temp) / 2, so
-// the solve yields y directly and the store phase needs no temp value: the second read of temp (7-12 % of such a launch) is gone
-// for every cell whose 64 lanes are NODE_IN; the other cells (line ends, masked geometry, dead lines) fetch temp for the lanes
-// that keep it.  Same equations, another rounding: the tolerance path only (tests/test_gpu_part.py, test_gpu_ref_golden.py).
-template <typename R, int DIR, int M, int NCH, int WPS, int LT, int PF = FS3D_PART_PF, int XB = 0, int OPF = FS3D_PART_OPF, bool KT = false, bool YF = false>
+template <typename R, int DIR, int M, int NCH, int WPS, int LT, int PF = FS3D_PART_PF, int XB = 0, int OPF = FS3D_PART_OPF, bool KT = false>
 __global__ void __launch_bounds__(LT * NCH, WPS) k_sweep_part(SweepParams<R> p, int n_o, int n_tiles, int order)
 {
-    static_assert(!YF || (XB == 0 && !KT), "y form: whole sweeps only");
     static_assert(DIR == 0 || DIR == 1, "lanes along k: X and Y sweeps");
     extern __shared__ __attribute__((aligned(16))) unsigned char part_smem[];
     static_assert(LT == 16 || LT == 32 || LT == 64, "lines per workgroup");
@@ -377,29 +371,6 @@ __global__ void __launch_bounds__(LT * NCH, WPS) k_sweep_part(SweepParams<R> p, 
                     for (int f = 0; f < 4; f++) { const R xr = p.xcarry_in[(long long)f * p.carry_pitch + cline]; dd[f] = s0 + i == n ? xr : dd[f]; }
                 }
             }
-            if constexpr (YF) {
-                // d' = (d + a temp[s-1] + b temp[s] + c temp[s+1]) / 2 with the row's own (a, b, c); INTERIOR rows:
-                // a = -q - vis, c = q - vis  ->  A temp = b temp[s] - vis (temp[s+1] + temp[s-1]) + q (temp[s+1] - temp[s-1])
-                if ((opq_s(umask) >> i) & 1u) {
-#pragma unroll
-                    for (int f = 0; f < 4; f++) {
-                        const R vis = f == 3 ? vis_t : vis_v, bb = f == 3 ? b_t : b_v;
-                        dd[f] = R(0.5) * pfma(qq, c.tp[f] - Tm[f], pfma(-vis, c.tp[f] + Tm[f], pfma(bb, Tc[f], dd[f])));
-                    }
-                } else {
-                    const int code4 = code_of(i), kind = code4 & 3;
-                    const bool is_int = kind == ROW_INTERIOR;
-#pragma unroll
-                    for (int f = 0; f < 4; f++) {
-                        const R vis = f == 3 ? vis_t : vis_v, bb = f == 3 ? b_t : b_v;
-                        const bool fr = (code4 & (f == 3 ? ROW_TEMPFREE : ROW_VELFREE)) != 0;
-                        const R ai = pfma(qq, c.tp[f] - Tm[f], pfma(-vis, c.tp[f] + Tm[f], bb * Tc[f]));
-                        // START / END rows: b = 2 (FREE) or 1, the one off-diagonal of a FREE row is -1; SKIP: identity
-                        const R an = (fr ? R(2) : R(1)) * Tc[f] - ((kind == ROW_END && fr) ? Tm[f] : R(0)) - ((kind == ROW_START && fr) ? c.tp[f] : R(0));
-                        dd[f] = R(0.5) * (dd[f] + (is_int ? ai : an));
-                    }
-                }
-            }
             q[i] = qq; dU[i] = dd[0]; dV[i] = dd[1]; dW[i] = dd[2];
             if constexpr (KT) {
 #pragma unroll
@@ -602,8 +573,7 @@ __global__ void __launch_bounds__(LT * NCH, WPS) k_sweep_part(SweepParams<R> p, 
             for (int f = 0; f < 4; f++) v[f] = x_nore ? R(f) : PBuf<R>::ld(Ltmp, vo, s_is + (unsigned)f * fsb);
             s_is = opq_s(s_is + ssb);
         };
-        const bool wave_dead = YF && __any(dead);       // y form: some lane of this wave keeps its temp values on every cell
-        if (p.merge && !KT && !YF) {
+        if (p.merge && !KT) {
 #pragma unroll
             for (int i = 0; i < OPF && i < M; i++) issue(tv[i]);
         }
@@ -611,37 +581,12 @@ __global__ void __launch_bounds__(LT * NCH, WPS) k_sweep_part(SweepParams<R> p, 
             constexpr int i = decltype(ic)::value;
             const unsigned sc = s_o;
             s_o = opq_s(s_o + ssb);
-            if (p.merge && !KT && !YF && i + OPF < M) issue(tv[(i + OPF) % (OPF + 1)]);
+            if (p.merge && !KT && i + OPF < M) issue(tv[(i + OPF) % (OPF + 1)]);
             __builtin_amdgcn_sched_barrier(0);
             R xv[4] = {dU[i], dV[i], dW[i], dT[i]};
             const bool uni = (opq_s(umask) >> i) & 1u;
             const bool seg = !dead && (uni || ((segm >> i) & 1u)), isin = !dead && (uni || ((inm >> i) & 1u));
             const bool in_line = i < nloc;
-            if constexpr (YF) {
-                // xv = y = the merged temp.  Lanes that are not NODE_IN (or dead) keep their temp value: fetched for those lanes only
-                // (every other lane of the load is out of range: no memory access), and only on cells / in waves that have such lanes
-                if (!uni || wave_dead) {
-                    const unsigned v_keep = (!isin && in_line) ? vo : PART_OOB;
-                    R tq[4];
-#pragma unroll
-                    for (int f = 0; f < 4; f++) tq[f] = PBuf<R>::ld(Ltmp, v_keep, sc + (unsigned)f * fsb);
-                    if (!uni && __any(isin && !seg)) {
-                        // NODE_IN cell outside every segment: the reference merges the stale `next` value with temp
-                        const unsigned v_st = (isin && !seg) ? vo : PART_OOB;
-#pragma unroll
-                        for (int f = 0; f < 4; f++) {
-                            const R sv = PBuf<R>::ld(Lnext, v_st, sc + (unsigned)f * fsb), tt = PBuf<R>::ld(Ltmp, v_st, sc + (unsigned)f * fsb);
-                            xv[f] = (isin && !seg) ? (tt + sv) * R(0.5) : xv[f];
-                        }
-                    }
-#pragma unroll
-                    for (int f = 0; f < 4; f++) xv[f] = isin ? xv[f] : tq[f];
-                }
-                const unsigned v_ = in_line ? vo_st : PART_OOB;
-#pragma unroll
-                for (int f = 0; f < 4; f++) PBuf<R>::template st<FS3D_PART_AUX_ST>(Ltout, v_, sc + (unsigned)f * fsb, xv[f]);
-                return;
-            }
             if (p.store_next) {
                 const unsigned v_ = seg ? vo_st : PART_OOB;            // UpdateSegment: every cell of a segment, nothing else
 #pragma unroll
@@ -672,10 +617,6 @@ __global__ void __launch_bounds__(LT * NCH, WPS) k_sweep_part(SweepParams<R> p, 
 #undef PSTAMP
 }
 
-// y form of the launches that store only the merged temp (k_sweep_part, YF): on unless a -DFS3D_EXPERIMENTS build is told
-// FS3D_PART_YFORM=0 (A/B measurements)
-static bool part_yform_enabled();
-
 // Kernel-experiment knobs (tile order, start delays, LDS padding, ...; FS3D_PART_ORDER bits 1/2 skip loads and give WRONG numbers):
 // read from the environment only in -DFS3D_EXPERIMENTS builds (build.build_variant); libfs3d_hip.so compiles the defaults in.
 #ifdef FS3D_EXPERIMENTS
@@ -684,15 +625,9 @@ static int part_exp_env(const char *name, int dflt) { const char *e = getenv(nam
 static constexpr int part_exp_env(const char *, int dflt) { return dflt; }
 #endif
 
-static bool part_yform_enabled() { static const int on = part_exp_env("FS3D_PART_YFORM", 1); return on != 0; }
-
-template <typename R, int DIR, int M, int NCH, int WPS, int LT, int PF = FS3D_PART_PF, int XB = 0, int OPF = FS3D_PART_OPF, bool KT = false, bool YF = false>
+template <typename R, int DIR, int M, int NCH, int WPS, int LT, int PF = FS3D_PART_PF, int XB = 0, int OPF = FS3D_PART_OPF, bool KT = false>
 static bool part_launch_xy(fs3d_ctx *c, const SweepParams<R> &p)
 {
-    if constexpr (!YF && XB == 0 && !KT) {
-        // launches that only store the merged temp: the y form (no second read of temp); FS3D_OPT... none: always, where it applies
-        if (p.merge == 1 && !p.store_next && !p.stamps && part_yform_enabled()) return part_launch_xy<R, DIR, M, NCH, WPS, LT, PF, XB, OPF, KT, true>(c, p);
-    }
     const int n_o = DIR == 0 ? p.dimy : (p.o_count ? p.o_count : p.dimx);
     const int n_tiles = (p.dimz + LT - 1) / LT;
     // FS3D_PART_LDSPAD (kernel experiments): more dynamic LDS than needed, to hold the workgroups per CU down
@@ -701,7 +636,7 @@ static bool part_launch_xy(fs3d_ctx *c, const SweepParams<R> &p)
     static std::atomic<unsigned long long> attr_set{0};
     const unsigned long long dev_bit = 1ull << (c->device & 63);
     if (!(attr_set.load() & dev_bit)) {
-        if (hipFuncSetAttribute((const void *)k_sweep_part<R, DIR, M, NCH, WPS, LT, PF, XB, OPF, KT, YF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        if (hipFuncSetAttribute((const void *)k_sweep_part<R, DIR, M, NCH, WPS, LT, PF, XB, OPF, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             c->err = std::string("partition kernel: hipFuncSetAttribute: ") + hipGetErrorString(hipGetLastError());
             return false;
         }
@@ -718,7 +653,7 @@ static bool part_launch_xy(fs3d_ctx *c, const SweepParams<R> &p)
     static const int late_slab = part_exp_env("FS3D_PART_LATE_SLAB", 0);   // experiment: slab kernels (XB != 0), delay units
     int order = order_env >= 0 ? order_env : (LT <= 32 ? (((long long)n_o * n_tiles < 1024 || NCH == 32) ? 1 : 0) | (late ? 0x40 | (4 << 8) : 0) : 0);
     if (XB != 0 && late_slab > 0 && LT * NCH <= 512 && (long long)n_o * n_tiles >= 512) order |= 0x40 | (late_slab << 8);
-    hipLaunchKernelGGL((k_sweep_part<R, DIR, M, NCH, WPS, LT, PF, XB, OPF, KT, YF>), dim3((unsigned)(n_o * n_tiles)), dim3(LT * NCH), lds, c->stream, p, n_o, n_tiles, order);
+    hipLaunchKernelGGL((k_sweep_part<R, DIR, M, NCH, WPS, LT, PF, XB, OPF, KT>), dim3((unsigned)(n_o * n_tiles)), dim3(LT * NCH), lds, c->stream, p, n_o, n_tiles, order);
     return true;
 }
 
