@@ -20,7 +20,7 @@ LAYER_CUR, LAYER_TEMP, LAYER_HALF, LAYER_NEXT = 0, 1, 2, 3
 SWEEP_AUTO, SWEEP_LINE, SWEEP_PIPE, SWEEP_PART, SWEEP_EXACT = 0, 1, 2, 3, 4
 KERNEL_NAMES = {0: "none", 1: "line", 2: "pipe", 3: "part"}
 OPT_SWEEP_KERNEL, OPT_FUSE_MERGE, OPT_DIV_CORE, OPT_XSOLVE, OPT_OVERLAP = 0, 1, 2, 3, 4
-XSOLVE_AUTO, XSOLVE_PIPELINED, XSOLVE_REDUCED = 0, 1, 2
+XSOLVE_AUTO, XSOLVE_PIPELINED, XSOLVE_REDUCED, XSOLVE_REDUCED_A2A = 0, 1, 2, 3
 
 # every symbol include/fs3d.h declares: name -> (restype, argtypes)
 _vp, _i, _d = C.c_void_p, C.c_int, C.c_double
@@ -212,7 +212,8 @@ class Solver:
             k, sg = C.c_int(0), C.c_int(0)
             self._chk(self.lib.fs3d_last_sweep_kernel(self.h, d, C.byref(k), C.byref(sg)))
             out[nm] = KERNEL_NAMES.get(k.value, str(k.value)) + ("-segmented" if sg.value & 1 else "") + \
-                {0: "", 1: "+pipelined-ranks", 2: "+reduced-interface", 3: "+reduced-interface(on-chip)"}[(sg.value >> 1) & 3]
+                {0: "", 1: "+pipelined-ranks", 2: "+reduced-interface", 3: "+reduced-interface(on-chip)"}[(sg.value >> 1) & 3] + \
+                ("+all-to-all" if sg.value & 8 else "")
         return out
 
     def profiler_events(self):

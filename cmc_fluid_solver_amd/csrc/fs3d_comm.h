@@ -13,4 +13,7 @@ fs3d_status fs3d_comm_allreduce_sum2(fs3d_ctx *c, double *dev2);
 fs3d_status fs3d_comm_xfer_rows(fs3d_ctx *c, void *dev, int nrows, size_t pitch, long long l0, long long l1, int peer, bool send);
 // all-gather of `count` elements per rank: recv = [rank][count] (send may not alias recv); one grouped exchange
 fs3d_status fs3d_comm_allgather(fs3d_ctx *c, const void *send, void *recv, size_t count);
+// all-to-all of `count` elements per pair of ranks: block r of `send` goes to rank r, block r of `recv` comes from rank r (the own block is a
+// device copy); one grouped exchange of point-to-point transfers -- one send and one receive per peer
+fs3d_status fs3d_comm_alltoall(fs3d_ctx *c, const void *send, void *recv, size_t count);
 extern "C" fs3d_status fs3d_comm_abort(fs3d_ctx *c);

@@ -245,6 +245,7 @@ void fs3d_comm_destroy(fs3d_ctx *c)
     if (c && c->comm) { ncclCommDestroy((ncclComm_t)c->comm); c->comm = nullptr; }
     if (c) c->local = nullptr;
     if (c) for (int i = 0; i < 4; i++) if (c->carry[i]) { hipFree(c->carry[i]); c->carry[i] = nullptr; }
+    if (c) for (int i = 0; i < 4; i++) if (c->xa2a[i]) { hipFree(c->xa2a[i]); c->xa2a[i] = nullptr; }
 }
 
 // one grouped exchange: every send and receive of `ops` is in flight together (no ordering deadlock)
@@ -314,6 +315,22 @@ fs3d_status fs3d_comm_allgather(fs3d_ctx *c, const void *send, void *recv, size_
         if (r == c->rank) continue;
         ops.push_back({(void *)send, count, r, true});
         ops.push_back({(char *)recv + (size_t)r * count * c->esize, count, r, false});
+    }
+    return exec_group(c, ops);
+}
+
+fs3d_status fs3d_comm_alltoall(fs3d_ctx *c, const void *send, void *recv, size_t count)
+{
+    const size_t bb = count * c->esize;
+    if (hipMemcpyAsync((char *)recv + (size_t)c->rank * bb, (const char *)send + (size_t)c->rank * bb, bb, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) {
+        c->err = "all-to-all: device copy of the own block failed"; return FS3D_ERR_HIP;
+    }
+    if (c->nranks == 1) return FS3D_OK;
+    std::vector<XOp> ops;
+    for (int r = 0; r < c->nranks; r++) {
+        if (r == c->rank) continue;
+        ops.push_back({(char *)send + (size_t)r * bb, count, r, true});
+        ops.push_back({(char *)recv + (size_t)r * bb, count, r, false});
     }
     return exec_group(c, ops);
 }

@@ -138,8 +138,10 @@ struct fs3d_ctx {
     int *errw_host = nullptr, *errw_dev = nullptr;   // pinned + mapped error word of the kernels (checked at every synchronisation)
     int rank = 0, nranks = 1;
     void *xif_send = nullptr, *xif_all = nullptr;   // reduced-interface X sweep: this slab's 18 words per line / all ranks'
+    void *xa2a[4] = {};            // distributed interface solve: packed words out / in, boundary values out / in ([rank][words][lines per rank])
     int opt_xsolve = 0;            // FS3D_OPT_XSOLVE: 0 auto, 1 pipelined (bit-exact), 2 reduced interface
     int ran_xsolve = 0;            // what the last cross-slab X sweep ran: 1 pipelined, 2 reduced interface, 3 reduced interface with the interface words from the partition kernel
+    int ran_xa2a = 0;              // ... and whether the interface solve was distributed over the ranks (two all-to-alls instead of one all-gather)
     int xblocks = 4;               // line blocks of the cross-slab X sweep pipeline (env FS3D_XBLOCKS)
     std::string err;
 };
@@ -158,4 +160,7 @@ template <typename R> void launch_xsweep_fwd(fs3d_ctx *c, const SweepParams<R> &
 // reduced-interface cross-slab X sweep: interface coefficients of this slab (18 words per line), the R x R interface solve
 template <typename R> void launch_xiface(fs3d_ctx *c, const SweepParams<R> &p, void *out);
 template <typename R> void launch_xreduce(fs3d_ctx *c, const void *all, long long nl, int nranks, int me, void *carry_in, void *xcarry_in);
+template <typename R> void launch_xpack(fs3d_ctx *c, const void *in, long long nl, long long lp, void *out);
+template <typename R> void launch_xreduce_a2a(fs3d_ctx *c, const void *all, long long nl, long long lp, int nranks, int me, void *out);
+template <typename R> void launch_xunpack(fs3d_ctx *c, const void *in, long long nl, long long lp, void *carry_in, void *xcarry_in);
 template <typename R> void launch_xsweep_bwd(fs3d_ctx *c, const SweepParams<R> &p, const void *xcarry_in, void *xcarry_out, long long l0, long long l1);

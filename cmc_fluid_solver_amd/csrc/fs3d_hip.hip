@@ -361,7 +361,7 @@ extern "C" fs3d_status fs3d_set_option(fs3d_ctx *c, int option, int value)
     case FS3D_OPT_DIV_CORE: c->opt_div_core = value ? 1 : 0; return FS3D_OK;
     case FS3D_OPT_OVERLAP: c->opt_overlap = value ? 1 : 0; return FS3D_OK;
     case FS3D_OPT_XSOLVE:
-        if (value < 0 || value > 2) return fail(c, FS3D_ERR_INVALID, "bad cross-slab X solve id");
+        if (value < 0 || value > 3) return fail(c, FS3D_ERR_INVALID, "bad cross-slab X solve id");
         c->opt_xsolve = value; return FS3D_OK;
     default: return fail(c, FS3D_ERR_INVALID, "unknown option");
     }
@@ -740,8 +740,31 @@ static fs3d_status xsweep_reduced(fs3d_ctx *c, SweepParams<R> &p)
         iface_done = launch_sweep_part<R>(c, 0, pa);
     }
     if (!iface_done) launch_xiface<R>(c, p, c->xif_send);
-    if ((st = fs3d_comm_allgather(c, c->xif_send, c->xif_all, 18 * pl))) return st;
-    launch_xreduce<R>(c, c->xif_all, (long long)pl, c->nranks, c->rank, c->carry[0], c->carry[2]);
+    // the R x R interface systems: every rank solves every line's (one all-gather), or -- three ranks and more -- every rank solves
+    // the lines it owns and hands every rank its two boundary values (two all-to-alls of point-to-point transfers: (R-1)/R x 26
+    // words per line on the wires instead of (R-1) x 18; same operations on the same values: bit-identical fields)
+    const bool a2a = c->opt_xsolve == 3 || (c->opt_xsolve != 2 && c->nranks >= 3);
+    c->ran_xa2a = a2a ? 1 : 0;
+    if (a2a) {
+        const long long lp = (((long long)pl + c->nranks - 1) / c->nranks + 63) / 64 * 64;       // lines per owner
+        const size_t w1 = (size_t)c->nranks * 18 * lp * c->esize, w2 = (size_t)c->nranks * 8 * lp * c->esize;
+        if (!c->xa2a[0]) {
+            const size_t sz[4] = {w1, w1, w2, w2};
+            for (int k = 0; k < 4; k++)
+                if (hipMalloc(&c->xa2a[k], sz[k]) != hipSuccess || hipMemsetAsync(c->xa2a[k], 0, sz[k], c->stream) != hipSuccess) {
+                    (void)hipGetLastError();
+                    return st = fail(c, FS3D_ERR_HIP, "distributed interface solve: hipMalloc of the exchange buffers failed");
+                }
+        }
+        launch_xpack<R>(c, c->xif_send, (long long)pl, lp, c->xa2a[0]);
+        if ((st = fs3d_comm_alltoall(c, c->xa2a[0], c->xa2a[1], (size_t)18 * lp))) return st;
+        launch_xreduce_a2a<R>(c, c->xa2a[1], (long long)pl, lp, c->nranks, c->rank, c->xa2a[2]);
+        if ((st = fs3d_comm_alltoall(c, c->xa2a[2], c->xa2a[3], (size_t)8 * lp))) return st;
+        launch_xunpack<R>(c, c->xa2a[3], (long long)pl, lp, c->carry[0], c->carry[2]);
+    } else {
+        if ((st = fs3d_comm_allgather(c, c->xif_send, c->xif_all, 18 * pl))) return st;
+        launch_xreduce<R>(c, c->xif_all, (long long)pl, c->nranks, c->rank, c->carry[0], c->carry[2]);
+    }
     p.carry_in = (const R *)c->carry[0]; p.carry_out = (R *)c->carry[1];
     p.xcarry_in = (const R *)c->carry[2]; p.xcarry_out = (R *)c->carry[3];
     c->ran_xsolve = iface_done ? 3 : 2;
@@ -828,9 +851,9 @@ static fs3d_status sweep_buffers(fs3d_ctx *c, int dir, double dt, int b_cur, int
     rec_begin(c, cls);
     // (a slab context without peers that asks for the reduced form runs its kernels on the slab alone: tools/slab_cost.py times
     // what one rank computes)
-    if (dir == 0 && (c->nranks > 1 || (c->opt_xsolve == 2 && (p.ghost_lo || p.ghost_hi)))) {
+    if (dir == 0 && (c->nranks > 1 || ((c->opt_xsolve == 2 || c->opt_xsolve == 3) && (p.ghost_lo || p.ghost_hi)))) {
         // reduced-interface form (all ranks at once) unless bit-equality with the sequential recurrence was asked for
-        const bool reduced = c->opt_xsolve == 2 || (c->opt_xsolve == 0 && c->nranks <= FS3D_XREDUCE_MAX_RANKS && (c->opt_kernel == FS3D_SWEEP_AUTO || c->opt_kernel == FS3D_SWEEP_PART));
+        const bool reduced = c->opt_xsolve == 2 || c->opt_xsolve == 3 || (c->opt_xsolve == 0 && c->nranks <= FS3D_XREDUCE_MAX_RANKS && (c->opt_kernel == FS3D_SWEEP_AUTO || c->opt_kernel == FS3D_SWEEP_PART));
         fs3d_status st = reduced ? xsweep_reduced<R>(c, p) : xsweep_multi<R>(c, p);
         rec_end(c);
         if (st) return st;
@@ -1143,7 +1166,7 @@ extern "C" fs3d_status fs3d_last_sweep_kernel(fs3d_ctx *c, int dir, int *kernel_
 {
     if (!c || dir < 0 || dir > 2 || !kernel_out) return FS3D_ERR_INVALID;
     *kernel_out = c->ran_kernel[dir];
-    if (segmented_out) *segmented_out = c->ran_segmented[dir] | (dir == 0 ? c->ran_xsolve << 1 : 0);
+    if (segmented_out) *segmented_out = c->ran_segmented[dir] | (dir == 0 ? (c->ran_xsolve << 1) | (c->ran_xa2a << 3) : 0);
     return FS3D_OK;
 }
 

@@ -293,6 +293,93 @@ __global__ void __launch_bounds__(256) k_xreduce(const R *all, long long nl, int
     for (int k = 0; k < 4; k++) { carry_in[(2 + k) * nl + tid] = xl[k]; xcarry_in[k * nl + tid] = xr[k]; }
 }
 
+// ---- (r3) the interface solve DISTRIBUTED over the ranks (FS3D_XSOLVE_REDUCED_A2A; xGMI is point-to-point: an all-gather delivers
+// every rank's 18 words of every line to every rank, (R-1) x 18 words per line received, and every rank then solves every line's
+// R x R system redundantly).  Here rank r owns the lines [r Lp, (r+1) Lp) of the plane:
+//   k_xpack        this slab's words [word][line] -> blocks [owner][word][line - owner Lp]      (one contiguous send per peer)
+//   all-to-all #1  rank r receives the words of ITS lines from every rank                       ((R-1)/R x 18 words per line)
+//   k_xreduce_a2a  per owned line: the R x R system once, then for EVERY rank the value below / above its slab -> [rank][8][line]
+//   all-to-all #2  the 8 boundary words per line back to the rank they belong to                 ((R-1)/R x 8 words per line)
+//   k_xunpack      blocks [owner][8][line] -> the carry layout of the slab solve
+// Same operations on the same values as k_xreduce: bit-identical to the all-gather form (tests/test_gpu_slabs.py).
+template <typename R>
+__global__ void __launch_bounds__(256) k_xpack(const R *in, long long nl, long long lp, R *out)
+{
+    const long long l = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= nl) return;
+    const long long r = l / lp, t = l - r * lp;
+    R *o = out + r * XIFACE_WORDS * lp + t;
+#pragma unroll
+    for (int w = 0; w < XIFACE_WORDS; w++) o[w * lp] = in[w * nl + l];
+}
+
+template <typename R>
+__global__ void __launch_bounds__(256) k_xreduce_a2a(const R *all, long long nl, long long lp, int nranks, int me, R *out)
+{
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= lp || (long long)me * lp + t >= nl) return;
+    const long long rs = (long long)XIFACE_WORDS * lp;          // one rank's block
+    auto W = [&](int r, int w) { return all[r * rs + w * lp + t]; };
+    for (int sys = 0; sys < 4; sys++) {
+        const int m = sys == 3 ? 5 : 0;
+        R cp[XREDUCE_MAXR], dq[XREDUCE_MAXR], X[XREDUCE_MAXR];
+        R c_ = R(0), d_ = R(0);
+        for (int r = 0; r < nranks; r++) {
+            const R lo = W(r, m + 0), cl = W(r, m + 2);
+            R di = W(r, m + 1), up = R(0), rhs = W(r, 10 + sys);
+            if (r + 1 < nranks) { di = di - cl * W(r + 1, m + 3); up = -cl * W(r + 1, m + 4); rhs = rhs - cl * W(r + 1, 14 + sys); }
+            const R den = di - lo * c_;
+            c_ = up / den; d_ = (rhs - lo * d_) / den;
+            cp[r] = c_; dq[r] = d_;
+        }
+        R x = dq[nranks - 1];
+        for (int r = nranks - 1; r >= 0; r--) {
+            if (r < nranks - 1) x = dq[r] - cp[r] * x;
+            X[r] = x;
+        }
+        for (int r = 0; r < nranks; r++) {
+            const R xl = r > 0 ? X[r - 1] : R(0);
+            const R xr = r + 1 < nranks ? W(r + 1, 14 + sys) - W(r + 1, m + 3) * X[r] - W(r + 1, m + 4) * X[r + 1] : R(0);
+            out[(long long)r * 8 * lp + sys * lp + t] = xl;
+            out[(long long)r * 8 * lp + (4 + sys) * lp + t] = xr;
+        }
+    }
+}
+
+template <typename R>
+__global__ void __launch_bounds__(256) k_xunpack(const R *in, long long nl, long long lp, R *carry_in, R *xcarry_in)
+{
+    const long long l = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= nl) return;
+    const long long s = l / lp, t = l - s * lp;
+    const R *b = in + s * 8 * lp + t;
+    carry_in[0 * nl + l] = R(0); carry_in[1 * nl + l] = R(0);
+#pragma unroll
+    for (int k = 0; k < 4; k++) { carry_in[(2 + k) * nl + l] = b[k * lp]; xcarry_in[k * nl + l] = b[(4 + k) * lp]; }
+}
+
+template <typename R>
+void launch_xpack(fs3d_ctx *c, const void *in, long long nl, long long lp, void *out)
+{
+    hipLaunchKernelGGL((k_xpack<R>), dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, c->stream, (const R *)in, nl, lp, (R *)out);
+}
+template <typename R>
+void launch_xreduce_a2a(fs3d_ctx *c, const void *all, long long nl, long long lp, int nranks, int me, void *out)
+{
+    hipLaunchKernelGGL((k_xreduce_a2a<R>), dim3((unsigned)((lp + 255) / 256)), dim3(256), 0, c->stream, (const R *)all, nl, lp, nranks, me, (R *)out);
+}
+template <typename R>
+void launch_xunpack(fs3d_ctx *c, const void *in, long long nl, long long lp, void *carry_in, void *xcarry_in)
+{
+    hipLaunchKernelGGL((k_xunpack<R>), dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, c->stream, (const R *)in, nl, lp, (R *)carry_in, (R *)xcarry_in);
+}
+template void launch_xpack<float>(fs3d_ctx *, const void *, long long, long long, void *);
+template void launch_xpack<double>(fs3d_ctx *, const void *, long long, long long, void *);
+template void launch_xreduce_a2a<float>(fs3d_ctx *, const void *, long long, long long, int, int, void *);
+template void launch_xreduce_a2a<double>(fs3d_ctx *, const void *, long long, long long, int, int, void *);
+template void launch_xunpack<float>(fs3d_ctx *, const void *, long long, long long, void *, void *);
+template void launch_xunpack<double>(fs3d_ctx *, const void *, long long, long long, void *, void *);
+
 template <typename R>
 void launch_xiface(fs3d_ctx *c, const SweepParams<R> &p, void *out)
 {

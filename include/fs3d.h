@@ -66,8 +66,10 @@ enum {
                                  sweep of the interior planes, the two edge planes follow; 0: exchange first, then one launch */
     FS3D_OPT_XSOLVE = 3,      /* cross-slab X sweep of a multi-GPU group: 1 = pipelined over the ranks (the reference's form,
                                  AdiSolver3D.cu:524-640; bit-equal to one GPU), 2 = reduced interface (every rank eliminates its slab
-                                 at once, one all-gather per sweep; equal to one GPU to rounding), 0 (default) = 2 unless the
-                                 sweep-kernel option asks for the bit-exact kernels */
+                                 at once; equal to one GPU to rounding) with ONE all-gather per sweep, every rank solving every line's
+                                 interface system, 3 = reduced interface with the interface solve distributed over the ranks (two
+                                 all-to-alls of point-to-point transfers; bit-identical to 2), 0 (default) = 3 from three ranks on,
+                                 2 for two ranks -- unless the sweep-kernel option asks for the bit-exact kernels (then 1) */
     FS3D_OPT_DIV_CORE = 2     /* 1 (default): fp32 pipe kernel divides with the scaling-free core of the IEEE expansion and
                                  falls back to the full division where an operand needs scaling (same results); 0: always full */
 };

@@ -212,3 +212,44 @@ def test_shipped_example_on_slabs_100_steps(nranks):
     for v in range(4):
         assert np.array_equal(ref[v], np.concatenate([res[r][0][v] for r in range(nranks)], axis=0)), "field %d" % v
     np.testing.assert_allclose(res[0][1], ref_err, rtol=1e-12)
+
+
+@pytest.mark.parametrize("nranks", [2, 3, 5, 8])
+@pytest.mark.parametrize("dtype,kernel", [(np.float32, capi.SWEEP_AUTO), (np.float32, capi.SWEEP_EXACT), (np.float64, capi.SWEEP_EXACT)])
+def test_distributed_interface_solve_equals_the_all_gather_form(built, nranks, dtype, kernel):
+    """(r3) FS3D_XSOLVE 3: every rank solves the R x R interface systems of the lines it owns and hands every rank its two boundary
+    values -- two all-to-alls of point-to-point transfers instead of one all-gather (xGMI is point-to-point: (R-1)/R x 26 words per
+    line on the wires instead of (R-1) x 18).  Same operations on the same values: the fields after two steps are BIT-IDENTICAL to
+    the all-gather form's, for uneven slabs, a plane whose line count is no multiple of the ranks, an obstacle across the cuts;
+    and the default picks it from three ranks on."""
+    from cmc_fluid_solver_amd import grids
+    g = grids.box_with_obstacle(67, 23, 64, h=0.02)              # 23 x 64 = 1472 lines: not a multiple of 3, 5, 8 x 64
+    params = capi.fluid_params(dtype, 200.0, 0.72, 1.4)
+
+    def run(xsolve):
+        grp = capi.LocalGroup(g, params, nranks, dtype)
+
+        def work(r, sv):
+            sv.set_option(capi.OPT_SWEEP_KERNEL, kernel)
+            if xsolve is not None:
+                sv.set_option(capi.OPT_XSOLVE, xsolve)
+            errs = []
+            for i in range(2):
+                sv.UpdateBoundaries(); errs.append(sv.TimeStep(0.1, 2, 2, True))
+            return sv.last_sweep_kernels()["X"], sv.download_layer(capi.LAYER_CUR), errs
+        try:
+            return grp.run(work)
+        finally:
+            grp.close()
+    ag, a2a = run(capi.XSOLVE_REDUCED), run(capi.XSOLVE_REDUCED_A2A)
+    assert all("all-to-all" in r[0] for r in a2a) and not any("all-to-all" in r[0] for r in ag)
+    for r in range(nranks):
+        for v in range(4):
+            assert np.array_equal(ag[r][1][v], a2a[r][1][v]), "slab %d field %d" % (r, v)
+        assert ag[r][2] == a2a[r][2]
+    if kernel == capi.SWEEP_AUTO:
+        dflt = run(None)
+        assert all(("all-to-all" in r[0]) == (nranks >= 3) and "reduced-interface" in r[0] for r in dflt), [r[0] for r in dflt]
+        for r in range(nranks):
+            for v in range(4):
+                assert np.array_equal(dflt[r][1][v], ag[r][1][v])

@@ -121,3 +121,60 @@ def test_slab_reduced_interface_solve_equals_thomas(tmp_path, world, dtype_name)
                     for l in range(nlines)], axis=1)
     err = np.linalg.norm(x - ref) / np.linalg.norm(ref)
     assert err <= (1e-14 if dtype_name == "float64" else 5e-7), err
+
+
+# ---- (r3) the interface solve distributed over the ranks: two all-to-alls instead of one all-gather ---------------------------------
+def _alltoall(send, rank, world):
+    """one grouped exchange of point-to-point transfers -- one send and one receive per peer, the own block copied (fs3d_comm_alltoall;
+    gloo has no all_to_all of its own)"""
+    recv = [torch.empty_like(t) for t in send]
+    recv[rank].copy_(send[rank])
+    reqs = [dist.isend(send[r], r) for r in range(world) if r != rank] + [dist.irecv(recv[r], r) for r in range(world) if r != rank]
+    for q in reqs:
+        q.wait()
+    return recv
+
+
+def _worker_a2a(rank, world, port, n, nlines, dtype_name, out_dir):
+    """fs3d_hip.hip: xsweep_reduced with FS3D_XSOLVE 3 -- rank r owns the lines [r Lp, (r+1) Lp): all-to-all #1 brings it every rank's
+    interface words of ITS lines, it solves their R x R systems once, all-to-all #2 hands every rank the value below and above its slab."""
+    from cmc_fluid_solver_amd import partition as pt
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dtype = np.dtype(dtype_name)
+    a, b, c, d = _make_system(n, nlines, dtype, seed=11)
+    x0, x1 = slab.slab_range(n, rank, world)
+    sl = slice(x0, x1)
+    co = pt.chunk_eliminate(a[sl], b[sl], c[sl], d[sl])
+    keys = ["A", "Bp", "cl", "Dp", "Vf", "Wf", "Gf"]
+    lp = -(-nlines // world)                                                  # lines per owner (the last block is padded)
+    mine = np.zeros((7, world * lp), dtype)
+    mine[:, :nlines] = np.stack([co[k] for k in keys])
+    send = [torch.from_numpy(np.ascontiguousarray(mine[:, r * lp:(r + 1) * lp])) for r in range(world)]      # k_xpack
+    recv = _alltoall(send, rank, world)                                       # #1: the words of MY lines from every rank
+    cos = [{k: g[i].numpy() for i, k in enumerate(keys)} for g in recv]
+    nown = max(0, min(lp, nlines - rank * lp))
+    X = np.zeros((world, lp), dtype)
+    if nown:
+        own = [{k: v[:nown] for k, v in cr.items()} for cr in cos]
+        X[:, :nown] = pt.thomas(*pt.reduced_rows(own))                        # k_xreduce_a2a: every system once
+    # the two boundary values of rank r on my lines: X_{r-1} and X_r (chunk_backsub derives x_first of the slab above from X_r itself)
+    out = [torch.from_numpy(np.stack([X[r - 1] if r else np.zeros(lp, dtype), X[r]])) for r in range(world)]
+    back = _alltoall(out, rank, world)                                        # #2
+    bv = np.concatenate([t.numpy() for t in back], axis=1)[:, :nlines]        # k_xunpack: [2, nlines]
+    x = pt.chunk_backsub(a[sl], b[sl], c[sl], d[sl], bv[0] if rank else None, bv[1])
+    np.save(os.path.join(out_dir, "xa_%d.npy" % rank), x)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [3, 8])
+def test_distributed_interface_solve_over_gloo(tmp_path, world):
+    """The all-to-all protocol between real processes (gloo here, RCCL on the GPUs): bit-identical to the all-gather form, for a line
+    count that is no multiple of the ranks (13 lines: the last owners hold padded or empty blocks)."""
+    n, nlines, dtype_name = 41, 13, "float64"
+    mp.spawn(_worker_reduced, args=(world, 29800 + world, n, nlines, dtype_name, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker_a2a, args=(world, 29850 + world, n, nlines, dtype_name, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / ("xr_%d.npy" % r)), np.load(tmp_path / ("xa_%d.npy" % r))), r
