@@ -147,6 +147,53 @@ __device__ __forceinline__ void part_step(R lead, R diag, R trail, R &cp, R &sp,
     for (int k = 0; k < NR; k++) asm volatile("" : "+v"(dp[k]));
 }
 
+// (r3) The velocity and the temperature matrix take the same elimination step on different coefficients, and the right-hand sides
+// come in pairs: U/V against the velocity matrix, W/T against (velocity, temperature).  In fp32 the step runs on 2-vectors --
+// v_pk_fma_f32 / v_pk_mul_f32 do two lanes' worth per issue slot: 18 packed + 2 v_rcp_f32 instead of 37 scalar instructions per step;
+// the kernels spend ~40 % of their time issuing VALU instructions.  Component for component the same
+// operations as part_step: the same bits.
+// Measured (profiles/r3_ab_packed.txt, interleaved, bit-identical fields): Z kernel (226 of 256 VGPRs, no spills) 0.2111 -> 0.2022 ms;
+// X/Y kernels 0.254 -> 0.275 / 0.245 -> 0.271 -- they sit at their 128-VGPR budget and the even-aligned register pairs cost 16-21
+// spilled registers.  Packed in the Z kernel only.
+#ifndef FS3D_PART_PACKED_XY
+#define FS3D_PART_PACKED_XY 0
+#endif
+#ifndef FS3D_PART_PACKED_Z
+#define FS3D_PART_PACKED_Z 1
+#endif
+typedef float pf2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pf2 pk_fma(pf2 a, pf2 b, pf2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ pf2 pk_quot(pf2 num, pf2 den, pf2 r)
+{
+    const pf2 q = num * r;
+    return FS3D_PART_QCORR ? pk_fma(pk_fma(-den, q, num), r, q) : q;
+}
+// lead/diag/trail: (a, b, c) going down, (c, b, a) going up, of the velocity (_v) and temperature (_t) matrix
+template <typename R, bool PK>
+__device__ __forceinline__ void part_step_vt(R lead_v, R diag_v, R trail_v, R lead_t, R diag_t, R trail_t, R &cpv, R &cpt, R &spv, R &spt,
+                                             R (&dp3)[3], R (&dp1)[1], const R (&d3)[3], const R (&d1)[1])
+{
+    if constexpr (std::is_same<R, float>::value && PK) {
+        const pf2 lead = {lead_v, lead_t}, diag = {diag_v, diag_t}, trail = {trail_v, trail_t};
+        pf2 cp = {cpv, cpt}, sp = {spv, spt};
+        const pf2 den = pk_fma(-lead, cp, diag);
+        pf2 r = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+        r = pk_fma(pk_fma(-den, r, pf2{1.0f, 1.0f}), r, r);
+        const pf2 lead_vv = lead.xx, den_vv = den.xx, r_vv = r.xx;
+        pf2 uv = {dp3[0], dp3[1]}, wt = {dp3[2], dp1[0]};
+        uv = pk_quot(pk_fma(-lead_vv, uv, pf2{d3[0], d3[1]}), den_vv, r_vv);
+        wt = pk_quot(pk_fma(-lead, wt, pf2{d3[2], d1[0]}), den, r);
+        sp = pk_quot(-lead * sp, den, r);
+        cp = pk_quot(trail, den, r);
+        asm volatile("" : "+v"(cp), "+v"(sp), "+v"(uv), "+v"(wt));       // pin: see part_step
+        cpv = cp.x; cpt = cp.y; spv = sp.x; spt = sp.y;
+        dp3[0] = uv.x; dp3[1] = uv.y; dp3[2] = wt.x; dp1[0] = wt.y;
+    } else {
+        part_step<R, 3>(lead_v, diag_v, trail_v, cpv, spv, dp3, d3);
+        part_step<R, 1>(lead_t, diag_t, trail_t, cpt, spt, dp1, d1);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // X / Y sweeps
 // ------------------------------------------------------------------------------------------------------------
@@ -406,10 +453,8 @@ __global__ void __launch_bounds__(LT * NCH, WPS) k_sweep_part(SweepParams<R> p, 
             PMat<R> mv, mt, nv, nt;
             coefs(i, mv, mt);
             coefs(j, nv, nt);
-            { const R d3[3] = {dU[i], dV[i], dW[i]}; part_step<R, 3>(mv.a, mv.b, mv.c, cpv, lpv, dp3, d3); }
-            { const R d1[1] = {tdi}; part_step<R, 1>(mt.a, mt.b, mt.c, cpt, lpt, dp1, d1); }
-            { const R d3[3] = {dU[j], dV[j], dW[j]}; part_step<R, 3>(nv.c, nv.b, nv.a, apv, upv, ep3, d3); }
-            { const R d1[1] = {tdj}; part_step<R, 1>(nt.c, nt.b, nt.a, apt, upt, ep1, d1); }
+            { const R d3[3] = {dU[i], dV[i], dW[i]}, d1[1] = {tdi}; part_step_vt<R, FS3D_PART_PACKED_XY != 0>(mv.a, mv.b, mv.c, mt.a, mt.b, mt.c, cpv, cpt, lpv, lpt, dp3, dp1, d3, d1); }
+            { const R d3[3] = {dU[j], dV[j], dW[j]}, d1[1] = {tdj}; part_step_vt<R, FS3D_PART_PACKED_XY != 0>(nv.c, nv.b, nv.a, nt.c, nt.b, nt.a, apv, apt, upv, upt, ep3, ep1, d3, d1); }
         });
         // the interface cell's own row with x[M-2] eliminated:  A X_{p-1} + Bp X_p + cl x_first(p+1) = Dp
         PMat<R> lv, lt;
@@ -546,8 +591,7 @@ __global__ void __launch_bounds__(LT * NCH, WPS) k_sweep_part(SweepParams<R> p, 
             if (i + 1 < M - 1) tdn = myD[(i + 1) * LT];
             PMat<R> mv, mt;
             coefs(i, mv, mt);
-            { const R d3[3] = {dU[i], dV[i], dW[i]}; part_step<R, 3>(mv.a, mv.b, mv.c, cpv, sp, dp3, d3); }
-            { const R d1[1] = {tdi}; part_step<R, 1>(mt.a, mt.b, mt.c, cpt, sp, dp1, d1); }
+            { const R d3[3] = {dU[i], dV[i], dW[i]}, d1[1] = {tdi}; R spt = sp; part_step_vt<R, FS3D_PART_PACKED_XY != 0>(mv.a, mv.b, mv.c, mt.a, mt.b, mt.c, cpv, cpt, sp, spt, dp3, dp1, d3, d1); }
             q[i] = cpv; cT[i] = cpt; dU[i] = dp3[0]; dV[i] = dp3[1]; dW[i] = dp3[2]; dT[i] = dp1[0];
         });
         dU[M - 1] = xo[0]; dV[M - 1] = xo[1]; dW[M - 1] = xo[2]; dT[M - 1] = xo[3];
@@ -906,8 +950,7 @@ __global__ void __launch_bounds__(256, WPS) k_sweep_part_z(SweepParams<float> p,
             R cv = R(0), lv = R(-1), ct = R(0), lt = R(-1), d3[3] = {R(0), R(0), R(0)}, d1[1] = {R(0)};
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                { const R dd3[3] = {d[0][c], d[1][c], d[2][c]}; part_step<R, 3>(mv[c].a, mv[c].b, mv[c].c, cv, lv, d3, dd3); }
-                { const R dd1[1] = {d[3][c]}; part_step<R, 1>(mt[c].a, mt[c].b, mt[c].c, ct, lt, d1, dd1); }
+                { const R dd3[3] = {d[0][c], d[1][c], d[2][c]}, dd1[1] = {d[3][c]}; part_step_vt<R, FS3D_PART_PACKED_Z != 0>(mv[c].a, mv[c].b, mv[c].c, mt[c].a, mt[c].b, mt[c].c, cv, ct, lv, lt, d3, d1, dd3, dd1); }
                 cpv[c] = cv; lpv[c] = lv; cpt[c] = ct; lpt[c] = lt;
                 dpd[c][0] = d3[0]; dpd[c][1] = d3[1]; dpd[c][2] = d3[2]; dpd[c][3] = d1[0];
             }
@@ -915,8 +958,7 @@ __global__ void __launch_bounds__(256, WPS) k_sweep_part_z(SweepParams<float> p,
         R apv = R(0), upv = R(-1), apt = R(0), upt = R(-1), ep3[3] = {R(0), R(0), R(0)}, ep1[1] = {R(0)};
 #pragma unroll
         for (int c = 2; c >= 0; c--) {
-            { const R dd3[3] = {d[0][c], d[1][c], d[2][c]}; part_step<R, 3>(mv[c].c, mv[c].b, mv[c].a, apv, upv, ep3, dd3); }
-            { const R dd1[1] = {d[3][c]}; part_step<R, 1>(mt[c].c, mt[c].b, mt[c].a, apt, upt, ep1, dd1); }
+            { const R dd3[3] = {d[0][c], d[1][c], d[2][c]}, dd1[1] = {d[3][c]}; part_step_vt<R, FS3D_PART_PACKED_Z != 0>(mv[c].c, mv[c].b, mv[c].a, mt[c].c, mt[c].b, mt[c].a, apv, apt, upv, upt, ep3, ep1, dd3, dd1); }
         }
         // ---- interface row (cell 3) with x[2] eliminated and x_first of the next lane substituted; normalised
         R av, cv_, at, ct_, dd[4];
@@ -948,7 +990,34 @@ __global__ void __launch_bounds__(256, WPS) k_sweep_part_z(SweepParams<float> p,
             if (at_cut && !hi) { ev = cv_; et = ct_; cv_ = R(0); ct_ = R(0); }
             if (at_cut && hi) { ev = av; et = at; av = R(0); at = R(0); }
         }
-        // ---- parallel cyclic reduction over the LPL lanes of the line
+        // ---- parallel cyclic reduction over the LPL lanes of the line.  (r3) on 2-vectors: (velocity, temperature) matrix words,
+        // right-hand sides U/V against the velocity matrix and W/T against (velocity, temperature): the same operations, component for
+        // component, as the scalar form (FS3D_PART_PACKED_Z 0), half the VALU issue slots
+        if constexpr (FS3D_PART_PACKED_Z != 0) {
+            pf2 A = {av, at}, C = {cv_, ct_}, D01 = {dd[0], dd[1]}, D23 = {dd[2], dd[3]}, E = {ev, et};
+            auto sh_up = [&](pf2 v, int s) __attribute__((always_inline)) { return pf2{__shfl_up(v.x, s, LPL), __shfl_up(v.y, s, LPL)}; };
+            auto sh_dn = [&](pf2 v, int s) __attribute__((always_inline)) { return pf2{__shfl_down(v.x, s, LPL), __shfl_down(v.y, s, LPL)}; };
+#pragma unroll
+            for (int s = 1; s < LPL; s <<= 1) {
+                const pf2 Am = sh_up(A, s), Cm = sh_up(C, s), Ap = sh_dn(A, s), Cp = sh_dn(C, s);
+                const pf2 Dm01 = sh_up(D01, s), Dm23 = sh_up(D23, s), Dq01 = sh_dn(D01, s), Dq23 = sh_dn(D23, s);
+                const bool has_m = l >= s, has_p = l + s < LPL;
+                const pf2 zero = {0.0f, 0.0f}, one = {1.0f, 1.0f};
+                const pf2 a = has_m ? A : zero, c = has_p ? C : zero;
+                const pf2 dn = pk_fma(-a, Cm, pk_fma(-c, Ap, one));
+                pf2 r = {__builtin_amdgcn_rcpf(dn.x), __builtin_amdgcn_rcpf(dn.y)};
+                r = pk_fma(pk_fma(-dn, r, one), r, r);
+                const pf2 avv = a.xx, cvv = c.xx, dvv = dn.xx, rvv = r.xx;
+                D01 = pk_quot(pk_fma(-avv, Dm01, pk_fma(-cvv, Dq01, D01)), dvv, rvv);
+                D23 = pk_quot(pk_fma(-a, Dm23, pk_fma(-c, Dq23, D23)), dn, r);
+                if (NW == 2) {
+                    const pf2 Em = sh_up(E, s), Eq = sh_dn(E, s);
+                    E = pk_quot(pk_fma(-a, Em, pk_fma(-c, Eq, E)), dn, r);
+                }
+                A = pk_quot(-a * Am, dn, r); C = pk_quot(-c * Cp, dn, r);
+            }
+            av = A.x; at = A.y; cv_ = C.x; ct_ = C.y; dd[0] = D01.x; dd[1] = D01.y; dd[2] = D23.x; dd[3] = D23.y; ev = E.x; et = E.y;
+        } else {
 #pragma unroll
         for (int s = 1; s < LPL; s <<= 1) {
             const R amv = __shfl_up(av, s, LPL), cmv = __shfl_up(cv_, s, LPL), apv_ = __shfl_down(av, s, LPL), cpv_ = __shfl_down(cv_, s, LPL);
@@ -971,6 +1040,7 @@ __global__ void __launch_bounds__(256, WPS) k_sweep_part_z(SweepParams<float> p,
             }
             av = pquot(-a_v * amv, dnv, rv); cv_ = pquot(-c_v * cpv_, dnv, rv);
             at = pquot(-a_t * amt, dnt, rt); ct_ = pquot(-c_t * cpt_, dnt, rt);
+        }
         }
         // ---- back-substitution: x[3] = X, x[c] = d'[c] - l[c] X_left - c'[c] x[c+1]
         R x[4][4];                                        // x[f][c]
