@@ -337,6 +337,20 @@ def test_full_size_256(built):
         assert a == pytest.approx(b, rel=1e-4)
     u = A[0].astype(np.float64)
     assert np.abs(u - u[:, ::-1, :]).max() <= 2e-5 * np.abs(u).max()            # y mirror (the partition is not mirror-symmetric in rounding)
+    # (r3) ... and directly against the CPU path at this size: the CPU oracle -- bit-equal to the reference's own
+    # binary at 256^3 (tests/test_ref_golden.py) -- walks the same 3 steps; the exact kernels must equal it bit for bit, the production
+    # kernels stay inside the distance bench.py publishes with the throughput (`parity_check`: 2.9e-6 / 1.7e-6 measured)
+    O = _oracle()
+    o = O.Oracle(g, capi.fluid_params(np.float32, *PARAMS), np.float32)
+    for i in range(3):
+        o.update_boundaries(); o.time_step(0.1, 4, 2, True)
+    E = o.get_layer_fields(O.L_CUR)
+    o.close()
+    for b, e in zip(B, E):
+        assert np.array_equal(b, e), "exact kernels differ from the CPU oracle at 256^3"
+    rv, rt = vec_rel(A, E), rel(A[3], E[3])
+    print("256^3 box after 3 steps: production kernels vs the CPU oracle: velocity %.2e, T %.2e" % (rv, rt))
+    assert rv <= 4.5e-6 and rt <= 2.6e-6
 
 
 def test_masked_geometry_256(built):
