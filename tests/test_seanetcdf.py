@@ -148,3 +148,19 @@ def test_a_btree_node_that_names_itself_is_refused(driver, tmp_path):
         hdf5_min.Hdf5File(str(bad)).read("z")
     r = subprocess.run([driver, str(bad), str(tmp_path / "out"), CONF, "--grid-only", str(tmp_path / "g.bin")], capture_output=True, text=True)
     assert r.returncode not in (0, -11, 139) and "HDF5" in (r.stderr + r.stdout), (r.returncode, r.stderr[-300:])
+
+
+def test_hdf5_reader_equals_the_real_hdf5_library():
+    """(r3) The own minimal HDF5 reader against the REAL library: tests/golden/white_sea_hdf5.npz holds every dataset of the reference's
+    white_sea_data.nc as `h5dump -b` of libhdf5 1.10 read it in the build container (tests/golden/make_hdf5_golden.py).  Bit for bit.
+    (The C++ reader is tied to this one cell for cell through the grids they produce: test_cpp_loader_equals_python_loader.)"""
+    z = np.load(os.path.join(os.path.dirname(INP), "white_sea_hdf5.npz"))
+    f = hdf5_min.Hdf5File(DATA)
+    names = [k for k in z.files if not k.endswith("_sha256")]
+    assert "z" in names
+    for n in names:
+        a = np.ascontiguousarray(f.read(n)).ravel()
+        assert a.size == z[n].size and np.array_equal(a.astype(z[n].dtype), z[n]), n
+        if a.dtype == z[n].dtype:
+            import hashlib
+            assert hashlib.sha256(a.tobytes()).hexdigest() == str(z[n + "_sha256"])
