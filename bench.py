@@ -137,6 +137,8 @@ def main():
                          % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the HIP path)")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit("bench.py --gpus %d: rank %d has no device (%d visible): one rank per GPU of ONE node" % (args.gpus, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
