@@ -56,6 +56,11 @@ CASES = {
     # the shipped 64^3 example, its own config, all 100 steps
     "box_pipe": dict(data="box_pipe_2D_data.txt", config="box_pipe_2D_config.txt", keys={}, align=True, prec=("f32", "f64"),
                      steps=100, full={}, hashed=(1, 2, 10, 50, 100), stride=2),
+    # other iteration counts (num_global / num_local) on the shipped example: the merge cadence of TimeStep / SolveDirection
+    "box_pipe_g1l3": dict(data="box_pipe_2D_data.txt", config="box_pipe_2D_config.txt", keys=dict(num_global="1", num_local="3", out_gridx="16", out_gridy="16", out_gridz="16"),
+                          align=True, prec=("f32", "f64"), steps=5, full={}, hashed=(1, 2, 5), stride=4),
+    "box_pipe_g3l1": dict(data="box_pipe_2D_data.txt", config="box_pipe_2D_config.txt", keys=dict(num_global="3", num_local="1", out_gridx="16", out_gridy="16", out_gridz="16"),
+                          align=True, prec=("f32", "f64"), steps=5, full={}, hashed=(1, 2, 5), stride=4),
     # the shipped masked-bottom example (depth_var 0.2)
     "non_uniform_pipe": dict(data="non_uniform_pipe_2D_data.txt", config="non_uniform_pipe_2D_config.txt", keys={}, align=True,
                              prec=("f32", "f64"), steps=20, full={}, hashed=(1, 2, 10, 20), stride=2),

@@ -19,6 +19,7 @@ INP = os.path.join(GOLD, "inputs")
 
 ALL = [("u_bend", "f32"), ("u_bend", "f64"), ("box_pipe", "f32"), ("box_pipe", "f64"), ("non_uniform_pipe", "f32"),
        ("non_uniform_pipe", "f64"), ("box128", "f32"), ("box128", "f64"), ("box256", "f32"), ("non_uniform256", "f32"),
+       ("box_pipe_g1l3", "f32"), ("box_pipe_g1l3", "f64"), ("box_pipe_g3l1", "f32"), ("box_pipe_g3l1", "f64"),
        ("heart_us", "f32"), ("box_pipe_3D", "f32"), ("tetra", "f32"), ("sphere_3D", "f32"), ("sphere_3D", "f64")]
 
 

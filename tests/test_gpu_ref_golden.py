@@ -58,13 +58,15 @@ def test_exact_kernels_equal_the_reference(built, name, prec):
 
 # (velocity, T) bounds per case for the fp32 production kernels against the REFERENCE's fp32 fields; measured (r3, one MI355X):
 #   u_bend 3.8e-7 / 8.5e-8, box_pipe (100 steps) 7.7e-7 / 1.7e-7, non_uniform_pipe 7.1e-7 / 1.3e-7, heart_us 3.7e-7 / 3.6e-7,
+#   box_pipe with num_global 1 / num_local 3: 1.15e-6 / 1.5e-7, with 3 / 1: 1.3e-6 / 1.6e-7 (5 steps from rest: fewer iterations per step
+#   leave the small early velocity field less settled than the shipped 4 / 2 does: 7.7e-7),
 #   box128 (10 steps) 2.2e-6 / 7.0e-7, box256 (3 steps) 4.2e-6 / 2.3e-6, non_uniform256 (2 steps) 3.2e-6 / 1.4e-6.
 # Up to 64^3 the 1e-6 of `north_star` holds.  At 128^3 and 256^3 it cannot hold for ANY fp32 evaluation order but the
 # reference's own: the line systems have condition number ~ b / (b - |a| - |c|) = 20 (128^3) ... 85 (256^3) at these h, so two
 # correct fp32 solves differ by kappa * 6e-8 = 1e-6 ... 5e-6 (the reference's own fp32 and fp64 builds differ by 2.6e-6 at 256^3
 # after 3 steps; the partition kernels sit CLOSER to that fp64 solution than the fp32 reference does: tests/test_gpu_part.py).
 # The bit-exact kernels (test above) meet the reference exactly at every size; these bounds are 1.5 x the measured distances.
-TOL = {"u_bend": (1e-6, 1e-6), "box_pipe": (1e-6, 1e-6), "non_uniform_pipe": (1e-6, 1e-6), "heart_us": (1e-6, 1e-6),
+TOL = {"u_bend": (1e-6, 1e-6), "box_pipe": (1e-6, 1e-6), "box_pipe_g1l3": (1.7e-6, 1e-6), "box_pipe_g3l1": (1.9e-6, 1e-6), "non_uniform_pipe": (1e-6, 1e-6), "heart_us": (1e-6, 1e-6),
        "box128": (3.4e-6, 1.1e-6), "box256": (6.4e-6, 3.5e-6), "non_uniform256": (4.8e-6, 2.1e-6),
        # Shape3D bodies are closed (no inflow): the only motion is the weak flow the T = 0 skin drives against T = 1 inside -- a stiff
        # boundary layer ("where the tolerance stops holding"); measured box_pipe_3D (128^3, 10 steps) 3.0e-6 / 8.0e-7,
