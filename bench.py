@@ -143,6 +143,19 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    # multi-rank runs have never met real wires: a rank that waits for ever in an exchange must not hold the
+    # node until the driver's clock runs out -- after 15 minutes the rank reports and leaves
+    if world > 1:
+        import threading
+
+        def _stuck():
+            sys.stderr.write("bench.py rank %d: no result after 900 s -- an exchange between the ranks is stuck; giving up\n" % rank)
+            sys.stderr.flush()
+            os._exit(5)
+        wd = threading.Timer(900.0, _stuck)
+        wd.daemon = True
+        wd.start()
+
     n = args.size
     dtype = np.float32 if args.dtype == "f32" else np.float64
     h = 1.0 / (n - 1)
