@@ -76,6 +76,10 @@ CASES = {
     "non_uniform256": dict(data="non_uniform_pipe_2D_data.txt", config="non_uniform_pipe_2D_config.txt",
                            keys=dict(grid_dx="0.0042", grid_dy="0.0042", grid_dz="0.0042", out_gridx="32", out_gridy="32", out_gridz="32"),
                            align=True, prec=("f32",), steps=2, full={}, hashed=(1, 2), stride=8),
+    # BASELINE configs[3]: 512^3 fp32 (the grid the 8-GPU run cuts into 64-plane slabs): one step, hashes + a 32^3 sample
+    "box512": dict(data="box_pipe_2D_data.txt", config="box_pipe_2D_config.txt",
+                   keys=dict(grid_dx="0.0021", grid_dy="0.0021", grid_dz="0.002", out_gridx="16", out_gridy="16", out_gridz="16"),
+                   align=True, prec=("f32",), steps=1, full={}, hashed=(1,), stride=16, big=True),
     # multi-frame Shape2D (moving walls + valve): adapted config (the shipped one is rejected by the reference's parser)
     "heart_us": dict(data="heart_us_2D_data.txt", config="heart_us_2D_config.txt", keys={}, align=True, prec=("f32",),
                      steps=8, full={}, hashed=(1, 2, 3, 4, 8), stride=2, grid_times="frames"),

@@ -127,3 +127,57 @@ def test_512_as_8_slabs_equals_one_context(built, box512):
     grp.close()
     for r in range(8):
         assert res[r][0][-1] == pytest.approx(errs[-1], rel=1e-12)
+
+
+def test_512_cubed_equals_the_reference(built):
+    """(r3) BASELINE configs[3]'s grid held to the REFERENCE ITSELF: tests/golden/ref_box512_f32.npz is one step of the reference's
+    own CPU build on the file-driven 512^3 box (grid_dx = grid_dy 0.0021, grid_dz 0.002: 112,135,625 NODE_IN cells).  The loader's
+    node arrays hash to the reference's; the bit-exact kernels -- one context, and the same grid as 8 x-slabs of 64 planes through
+    the in-process group with the rank pipeline -- return its fields bit for bit (sha256 of the raw arrays); the production
+    kernels stay within the stated distance on the fixture's strided sample."""
+    import refgolden as RG
+    from cmc_fluid_solver_amd.slab import slab_range
+    fx = RG.Fixture("box512", "f32")
+    m = fx.meta
+    nodes, cfg, dt = fx.loader()
+    assert nodes.shape == (512, 512, 512) and nodes.count(grids.NODE_IN) == m["node_in"] == 112135625
+    assert RG.sha(nodes.type) == m["nodes_sha"]["type"] and RG.sha(np.asarray(nodes.T, np.float32)) == m["nodes_sha"]["T"]
+    params = fx.params()
+    step_dt, G, L = fx.step_dt(), cfg.num_global, cfg.num_local
+    want = m["step_sha"]["1"]
+
+    s = capi.Solver(nodes, params, np.float32)
+    s.set_option(capi.OPT_SWEEP_KERNEL, capi.SWEEP_EXACT)
+    s.UpdateBoundaries(); err = s.TimeStep(step_dt, G, L, True)
+    one = s.download_layer(capi.LAYER_CUR)
+    s.close()
+    for v, a in zip("UVWT", one):
+        assert RG.sha(a) == want[v], "%s after step 1 differs from the reference at 512^3" % v
+    assert "%.8f" % err == "%.8f" % m["err_trace"][0]
+    del one
+
+    grp = capi.LocalGroup(nodes, params, 8, np.float32)
+
+    def work(r, sv):
+        sv.set_option(capi.OPT_SWEEP_KERNEL, capi.SWEEP_EXACT)
+        sv.UpdateBoundaries(); e = sv.TimeStep(step_dt, G, L, True)
+        return sv.download_layer(capi.LAYER_CUR), e
+    res = grp.run(work)
+    grp.close()
+    assert [slab_range(512, r, 8) for r in range(8)] == [(64 * r, 64 * r + 64) for r in range(8)]
+    for k, v in enumerate("UVWT"):
+        assert RG.sha(np.concatenate([res[r][0][k] for r in range(8)], axis=0)) == want[v], "8 slabs: %s differs from the reference" % v
+    assert all(r[1] == pytest.approx(m["step_err"]["1"], rel=1e-10) for r in res)
+    del res
+
+    s = capi.Solver(nodes, params, np.float32)
+    s.UpdateBoundaries(); s.TimeStep(step_dt, G, L, True)
+    got = [a[::16, ::16, ::16] for a in s.download_layer(capi.LAYER_CUR)]
+    assert set(s.last_sweep_kernels().values()) == {"part"}
+    s.close()
+    smp = [fx.sample(v, 1) for v in "UVWT"]
+    mask = fx.z["node_type"][::16, ::16, ::16] != 1
+    vel = RG.rel_l2(np.stack(got[:3]), np.stack(smp[:3]), np.stack([mask] * 3))
+    tt = RG.rel_l2(got[3], smp[3], mask)
+    print("512^3 step 1: production kernels vs the reference: velocity %.3g  T %.3g" % (vel, tt))
+    assert vel <= 5.7e-6 and tt <= 3.6e-6           # measured 3.8e-6 / 2.4e-6 (condition number of the line systems ~ 340 at h = 1/511)
