@@ -307,7 +307,13 @@ def main():
         # The fused time step does not store `next` in the local iterations whose `next` the following one overwrites
         # unread ((L-1) of every L launches of a class): those launches move 12 words/cell.  `achieved` is priced on
         # the launch mix actually issued, not on the 16-word figure.
-        words = 16.0 - 4.0 * (NUM_LOCAL - 1) / NUM_LOCAL
+        # (r3) The X sweep that closes a global iteration but the last does not store it either (the next iteration's Z sweep
+        # overwrites it unread), and the step's very last X sweep stores `next` but no merged temp (the next step starts from
+        # temp := cur): every X launch moves 12 words/cell.
+        skip = (NUM_LOCAL - 1) / NUM_LOCAL
+        skip_x = 1.0
+        skip_k = skip_x if names[k] == "sweep_X" else skip
+        words = 16.0 - 4.0 * skip_k
         alg_bytes = int(words * esize * local_cells)
         achieved = alg_bytes / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
         # HBM bytes per launch of the dominant kernel from the PMC passes (collected separately, profiles/)
@@ -341,7 +347,7 @@ def main():
                          "device_copy_GBps": copy_gbps,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "algorithmic_bytes_per_launch_all_stores": ref_alg_bytes,
-                         "launches_without_next_store": "%d of every %d per sweep class" % (NUM_LOCAL - 1, NUM_LOCAL),
+                         "launches_moving_12_words_per_cell": {"sweep_Z": round(skip, 4), "sweep_Y": round(skip, 4), "sweep_X": round(skip_x, 4)},
                          "per_class_ms_per_launch": {nm: round(ms_cls[j] / max(1, n_cls[j]), 4)
                                                      for j, nm in enumerate(names + ["other"])},
                          "launches": dict(zip(names + ["other"], n_cls)),
@@ -349,7 +355,7 @@ def main():
                          "step_frac_of_hbm_roofline_1760B": round(
                              (cells * 1760.0 * (esize / 4) * args.steps / sec / 1e9) / (HBM_PEAK_GBS * world), 4),
                          "step_frac_of_hbm_roofline_moved": round(
-                             (cells * (1760.0 - 16.0 * 3 * NUM_GLOBAL * (NUM_LOCAL - 1)) * (esize / 4) * args.steps / sec / 1e9)
+                             (cells * (1760.0 - 32.0 - 48.0 * NUM_GLOBAL - 16.0 * NUM_GLOBAL * (3 * NUM_LOCAL * skip + (skip_x - skip) * NUM_LOCAL)) * (esize / 4) * args.steps / sec / 1e9)
                              / (HBM_PEAK_GBS * world), 4)},
         }
         if mgpu_check is not None:

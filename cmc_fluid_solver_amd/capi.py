@@ -19,7 +19,7 @@ DIR_X, DIR_Y, DIR_Z = 0, 1, 2
 LAYER_CUR, LAYER_TEMP, LAYER_HALF, LAYER_NEXT = 0, 1, 2, 3
 SWEEP_AUTO, SWEEP_LINE, SWEEP_PIPE, SWEEP_PART, SWEEP_EXACT = 0, 1, 2, 3, 4
 KERNEL_NAMES = {0: "none", 1: "line", 2: "pipe", 3: "part"}
-OPT_SWEEP_KERNEL, OPT_FUSE_MERGE, OPT_DIV_CORE, OPT_XSOLVE, OPT_OVERLAP = 0, 1, 2, 3, 4
+OPT_SWEEP_KERNEL, OPT_FUSE_MERGE, OPT_DIV_CORE, OPT_XSOLVE, OPT_OVERLAP, OPT_KEEP_TEMP = 0, 1, 2, 3, 4, 5
 XSOLVE_AUTO, XSOLVE_PIPELINED, XSOLVE_REDUCED, XSOLVE_REDUCED_A2A = 0, 1, 2, 3
 
 # every symbol include/fs3d.h declares: name -> (restype, argtypes)

@@ -96,6 +96,7 @@ struct fs3d_ctx {
     void *bnd_val[4] = {};
     int n_bnd = 0;
     int nseg[3] = {0, 0, 0};
+    long long stale_in_cells = 0;  // NODE_IN cells on no segment of some direction (they merge stale `next` values): 0 for closed geometries
     // div error partials
     double *red_buf = nullptr;     // device
     double *red_host = nullptr;    // pinned
@@ -107,6 +108,7 @@ struct fs3d_ctx {
     hipStream_t xstream = nullptr;         // the stream the transport works on right now (stream or comm_stream)
     hipEvent_t ev_src = nullptr, ev_halo = nullptr;
     int opt_overlap = 1;                   // FS3D_OPT_OVERLAP
+    int opt_keep_temp = 0;                 // FS3D_OPT_KEEP_TEMP
     // options
     int opt_kernel = FS3D_SWEEP_AUTO;
     int ran_kernel[3] = {0, 0, 0};   // per direction: the kernel the last sweep really ran (fs3d_last_sweep_kernel)

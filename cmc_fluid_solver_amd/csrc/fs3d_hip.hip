@@ -360,6 +360,7 @@ extern "C" fs3d_status fs3d_set_option(fs3d_ctx *c, int option, int value)
     case FS3D_OPT_FUSE_MERGE: c->opt_fuse = value ? 1 : 0; return FS3D_OK;
     case FS3D_OPT_DIV_CORE: c->opt_div_core = value ? 1 : 0; return FS3D_OK;
     case FS3D_OPT_OVERLAP: c->opt_overlap = value ? 1 : 0; return FS3D_OK;
+    case FS3D_OPT_KEEP_TEMP: c->opt_keep_temp = value ? 1 : 0; return FS3D_OK;
     case FS3D_OPT_XSOLVE:
         if (value < 0 || value > 3) return fail(c, FS3D_ERR_INVALID, "bad cross-slab X solve id");
         c->opt_xsolve = value; return FS3D_OK;
@@ -497,6 +498,14 @@ static fs3d_status upload_nodes_impl(fs3d_ctx *c, const uint8_t *type, const uin
         // dead lines: no cell of the (local part of the) line is on a segment of that direction or NODE_IN -- nothing a
         // sweep computes for such a line is ever stored; the partition kernels keep them off the row-kind paths
         const long long nl[3] = {(long long)dy * dz, (long long)nx * dz, (long long)nx * dy};
+        // NODE_IN cells that lie on no segment of some direction (a run without a closing cell, Grid3D.cpp:87-117): the reference merges
+        // the STALE `next` value there -- whatever an earlier sweep left.  Only a geometry without such cells lets the time step drop
+        // stores of `next` that nothing but they could read (time_step_enqueue).
+        long long stale = 0;
+        for (long long l = 0; l < c->ncell; l++)
+            if (((code[(size_t)l] >> CODE_TYPE_SHIFT) & 3) == FS3D_NODE_IN)
+                for (int d = 0; d < 3; d++) stale += ((code[(size_t)l] >> (4 * d)) & 3) == ROW_SKIP;
+        c->stale_in_cells = stale;
         for (int d = 0; d < 3; d++) {
             std::vector<uint8_t> dead((size_t)nl[d], 1);
             for (long long l = 0; l < c->ncell; l++) {
@@ -1103,8 +1112,17 @@ static fs3d_status time_step_enqueue(fs3d_ctx *c, double dt, int G, int L, bool 
                 for (int l = 0; l < L; l++) {
                     // `next` of a local iteration that is not the last of its direction is overwritten by the following
                     // one without having been read (the merge into temp is fused into the kernel): not stored
-                    const int merge = ((d == 2 && l == L - 1) ? 2 : 1) | (l < L - 1 ? 4 : 0);
-                    if ((st = sweep_buffers<R>(c, plan[d][0], dt, plan[d][1], bTin, plan[d][2], bTout, merge, true))) return st;
+                    // (r3) ... and so is the `next` of the X sweep that closes a global iteration but the last: the Z sweep of the
+                    // following iteration writes `next` on every segment cell before anything reads it (Y reads it as its `cur` on
+                    // interior rows only; the result layer is the LAST iteration's) -- provided no NODE_IN cell relies on stale values
+                    const bool x_dead = d == 2 && l == L - 1 && it < G - 1 && c->stale_in_cells == 0;
+                    int merge = ((d == 2 && l == L - 1) ? 2 : 1) | ((l < L - 1 || x_dead) ? 4 : 0);
+                    // (r3) the merged temp of the step's very last sweep is dead too: the next step starts from temp := cur (:320),
+                    // GetLayer / EvalDivError read `next` (FS3D_OPT_KEEP_TEMP 1 stores it, as the reference's private member holds it)
+                    const bool last_sweep = it == G - 1 && d == 2 && l == L - 1;
+                    if (last_sweep && !c->opt_keep_temp && bTin != bCur) merge = 0;
+                    if ((st = sweep_buffers<R>(c, plan[d][0], dt, plan[d][1], bTin, plan[d][2], merge ? bTout : bTin, merge, true))) return st;
+                    if (merge == 0) continue;                                  // temp stays where it is
                     if (bTin == bCur) { bTin = bTout; bTout = bSpare; }
                     else { int t = bTin; bTin = bTout; bTout = t; }
                 }

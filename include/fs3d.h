@@ -70,6 +70,10 @@ enum {
                                  interface system, 3 = reduced interface with the interface solve distributed over the ranks (two
                                  all-to-alls of point-to-point transfers; bit-identical to 2), 0 (default) = 3 from three ranks on,
                                  2 for two ranks -- unless the sweep-kernel option asks for the bit-exact kernels (then 1) */
+    FS3D_OPT_KEEP_TEMP = 5,   /* 0 (default): the merged temp of the LAST sweep of a fused time step is not computed or stored -- nothing
+                                 reads it: the next step starts from temp := cur (AdiSolver3D.cpp:320), GetLayer and EvalDivError read
+                                 `next`; FS3D_LAYER_TEMP then holds the iterate before that last merge.  1: store it, as the
+                                 reference's private `temp` member holds it after TimeStep (the parity tests that download it) */
     FS3D_OPT_DIV_CORE = 2     /* 1 (default): fp32 pipe kernel divides with the scaling-free core of the IEEE expansion and
                                  falls back to the full division where an operand needs scaling (same results); 0: always full */
 };

@@ -34,6 +34,7 @@ def make_pair(g, dtype, kernel=capi.SWEEP_EXACT, fuse=1):
     s = capi.Solver(g, params, dtype)
     s.set_option(capi.OPT_SWEEP_KERNEL, kernel)
     s.set_option(capi.OPT_FUSE_MERGE, fuse)
+    s.set_option(capi.OPT_KEEP_TEMP, 1)          # these tests download the private `temp` layer after whole time steps
     o = O.Oracle(g, params, dtype)
     return s, o
 
@@ -592,3 +593,30 @@ def test_dead_lines_inside_the_fluid(built, kernel, dtype, big):
             assert rc == 0 and e == pytest.approx(eo, rel=1e-12)
             assert_layers_equal(s, o, capi.LAYER_CUR, O.L_CUR, "cur after step %d" % step)
             assert_layers_equal(s, o, capi.LAYER_TEMP, O.L_TEMP, "temp after step %d" % step)
+
+
+@pytest.mark.parametrize("kernel", [capi.SWEEP_EXACT, capi.SWEEP_AUTO])
+def test_dead_stores_of_the_fused_step_are_dead(built, kernel):
+    """(r3) The fused time step drops two kinds of stores nothing reads: `next` of the X sweep that closes a global iteration but the
+    last (the next iteration's Z sweep overwrites it), and the merged temp of the step's very last sweep (the next step starts from
+    temp := cur).  Everything observable -- cur / next after every step, diffError, GetLayer -- is bit-identical with and without them
+    (FS3D_OPT_KEEP_TEMP, and the unfused step as the plain statement of AdiSolver3D::TimeStep), on a masked geometry, 4 steps."""
+    g = grids.box_with_obstacle(40, 36, 32, h=0.03)
+    params = capi.fluid_params(np.float32, *PARAMS)
+    outs = []
+    for keep, fuse in ((0, 1), (1, 1), (1, 0)):
+        s = capi.Solver(g, params, np.float32)
+        s.set_option(capi.OPT_SWEEP_KERNEL, kernel); s.set_option(capi.OPT_FUSE_MERGE, fuse); s.set_option(capi.OPT_KEEP_TEMP, keep)
+        rec = []
+        for step in range(4):
+            s.UpdateBoundaries()
+            rec.append(s.TimeStep(DT, 3, 2, True))
+            rec += s.download_layer(capi.LAYER_CUR) + s.download_layer(capi.LAYER_NEXT) + list(s.GetLayer((9, 8, 7)))
+        outs.append(rec)
+        s.close()
+    fused_keep, unfused = outs[1], outs[2]
+    for a, b in zip(outs[0], fused_keep):
+        assert np.array_equal(a, b)
+    if kernel == capi.SWEEP_EXACT:                       # the exact kernels' fused step equals the unfused one bit for bit
+        for a, b in zip(outs[0], unfused):
+            assert np.array_equal(a, b)
