@@ -1,3 +1,5 @@
+"""sha256 of the fields after two steps on a masked grid: run it with two builds (FS3D_LIB_PATH) to see whether a kernel change
+kept the bits (packed math did, other contractions do not).  python tools/hash_fields.py   (GPU box)"""
 import sys, hashlib, numpy as np
 sys.path.insert(0, '.')
 from cmc_fluid_solver_amd import capi, grids
