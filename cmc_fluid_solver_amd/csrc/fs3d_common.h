@@ -35,6 +35,12 @@ struct SweepParams {
     long long fstride;          // elements between consecutive fields of a layer
     const uint16_t *code;
     const uint8_t *dead;        // per line of the sweep direction: 1 = no cell of the line is on a segment or NODE_IN (partition kernels)
+    // (r3) shared code columns of the X / Y partition kernels: where every live line of a group of 32 neighbouring lines carries the
+    // same row codes (a box: all of them), the group reads ONE column of codes instead of 2 bytes per cell from HBM
+    const uint16_t *ucol;       // [column id][UCOL_PITCH] the distinct columns (bits as in `code`), or nullptr -- a box has three of them: hot in the caches
+    const unsigned *uflag;      // [o][group]: bit 0 the group is uniform, bit 1 so is the pair (group, group + 1) with equal columns (64-line tiles),
+                                // bits 2.. the id of the group's (pair's) column
+    int ung;                    // groups per row / plane: ceil(dimz / 32)
     const R *node_;             // node boundary values (v.x, v.y, v.z, T), field v at + v*nstride
     R *scr_;                    // LINE kernel scratch: c'_uvw, c'_T, d'_U, d'_V, d'_W, d'_T at + v*nstride
     long long nstride;          // elements between consecutive fields of node_ / scr_ (>= number of owned cells)
@@ -68,6 +74,7 @@ struct SweepParams {
     int store_next;             // pipe kernel, fused time step: 0 when a later local iteration overwrites `next` unread (only the merge uses x)
 };
 
+#define UCOL_PITCH 512                 // codes per shared column (the partition kernels take lines of <= 512 cells)
 #define FS3D_XREDUCE_MAX_RANKS 64      // k_xreduce (kernels_line.hip) holds the R x R slab system of a line in per-thread arrays of this size
 
 struct fs3d_ctx {
@@ -87,6 +94,8 @@ struct fs3d_ctx {
     int slot[4] = {0, 1, 2, 3}; // layer id -> buffer
     int spare = 4;
     uint16_t *code = nullptr;
+    uint16_t *ucol[2] = {};     // shared code columns of the X / Y partition kernels (SweepParams::ucol)
+    unsigned *uflag[2] = {};
     uint8_t *dead[3] = {};      // per direction, one byte per line: the line has no segment cell and no NODE_IN cell (X: [j][k], Y: [i][k], Z: [i][j])
     void *node = nullptr;       // 4 x ncell
     void *scr = nullptr;        // >= 6 x ncell: rows of the thread-per-line kernel / of the pipe kernel's halves (allocated on demand)

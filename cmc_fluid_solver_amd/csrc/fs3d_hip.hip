@@ -7,6 +7,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <string>
 #include <type_traits>
 
 #include "fs3d_common.h"
@@ -325,6 +327,7 @@ extern "C" void fs3d_destroy(fs3d_ctx *c)
     for (int i = 0; i < 2; i++) if (c->seg_carry[i]) hipFree(c->seg_carry[i]);
     if (c->code) hipFree(c->code);
     for (int d = 0; d < 3; d++) if (c->dead[d]) hipFree(c->dead[d]);
+    for (int d = 0; d < 2; d++) { if (c->ucol[d]) hipFree(c->ucol[d]); if (c->uflag[d]) hipFree(c->uflag[d]); }
     if (c->node) hipFree(c->node);
     if (c->scr) hipFree(c->scr);
     if (c->xif_send) hipFree(c->xif_send);
@@ -516,6 +519,64 @@ static fs3d_status upload_nodes_impl(fs3d_ctx *c, const uint8_t *type, const uin
             if (c->dead[d]) { hipFree(c->dead[d]); c->dead[d] = nullptr; }
             HIPCHK(c, hipMalloc((void **)&c->dead[d], (size_t)nl[d]));
             HIPCHK(c, hipMemcpy(c->dead[d], dead.data(), (size_t)nl[d], hipMemcpyHostToDevice));
+            if (d < 2) {
+                // shared code columns (X: o = j, line cells along i; Y: o = i, cells along j; lanes k in groups of 32): a group is
+                // uniform when all its live lines carry the same (row code of this direction, node type) on every cell
+                if (c->ucol[d]) { hipFree(c->ucol[d]); c->ucol[d] = nullptr; }
+                if (c->uflag[d]) { hipFree(c->uflag[d]); c->uflag[d] = nullptr; }
+                const int n_o = d == 0 ? dy : nx, n = d == 0 ? nx : dy, ng = (dz + 31) / 32;
+                if (n <= UCOL_PITCH) {
+                    const uint16_t keep = (uint16_t)((0xF << (4 * d)) | (3 << CODE_TYPE_SHIFT));
+                    const long long ss = d == 0 ? plane : dz, os = d == 0 ? (long long)dz : plane;
+                    std::vector<uint16_t> col((size_t)n_o * ng * UCOL_PITCH, 0);
+                    std::vector<uint8_t> flag((size_t)n_o * ng, 0);
+                    for (int o = 0; o < n_o; o++)
+                        for (int g = 0; g < ng; g++) {
+                            uint16_t *cc = &col[((size_t)o * ng + g) * UCOL_PITCH];
+                            int k0 = -1;
+                            bool uni = true;
+                            for (int k = 32 * g; k < std::min(32 * g + 32, dz) && uni; k++) {
+                                if (dead[(size_t)o * dz + k]) continue;
+                                const uint16_t *src = &code[(size_t)((long long)o * os + k)];
+                                if (k0 < 0) { k0 = k; for (int s2 = 0; s2 < n; s2++) cc[s2] = (uint16_t)(src[(size_t)s2 * ss] & keep); }
+                                else for (int s2 = 0; s2 < n; s2++) if ((uint16_t)(src[(size_t)s2 * ss] & keep) != cc[s2]) { uni = false; break; }
+                            }
+                            flag[(size_t)o * ng + g] = uni ? 1 : 0;
+                        }
+                    for (int o = 0; o < n_o; o++)
+                        for (int g = 0; g < ng; g += 2) {
+                            bool pair = flag[(size_t)o * ng + g] & 1;
+                            if (pair && g + 1 < ng) {
+                                pair = flag[(size_t)o * ng + g + 1] & 1;
+                                // an all-dead group holds zeros: it takes the other group's column
+                                const uint16_t *a = &col[((size_t)o * ng + g) * UCOL_PITCH], *b = a + UCOL_PITCH;
+                                bool da = true, db = true;
+                                for (int k = 32 * g; k < std::min(32 * g + 32, dz); k++) da = da && dead[(size_t)o * dz + k];
+                                for (int k = 32 * g + 32; k < std::min(32 * g + 64, dz); k++) db = db && dead[(size_t)o * dz + k];
+                                if (pair && da && !db) std::copy(b, b + UCOL_PITCH, &col[((size_t)o * ng + g) * UCOL_PITCH]);
+                                else if (pair && !da && !db) pair = std::equal(a, a + n, b);
+                            }
+                            if (pair) flag[(size_t)o * ng + g] |= 2;
+                        }
+                    // the distinct columns only (a box has three: interior lines, and the rows / planes at the faces): they stay in the caches
+                    std::map<std::string, unsigned> ids;
+                    std::vector<uint16_t> uniq;
+                    std::vector<unsigned> fl(flag.size(), 0);
+                    for (size_t q = 0; q < flag.size(); q++) {
+                        if (!flag[q]) continue;
+                        const uint16_t *cc = &col[q * UCOL_PITCH];
+                        const std::string key((const char *)cc, (size_t)n * sizeof(uint16_t));
+                        auto it = ids.find(key);
+                        if (it == ids.end()) { it = ids.emplace(key, (unsigned)(uniq.size() / UCOL_PITCH)).first; uniq.insert(uniq.end(), cc, cc + UCOL_PITCH); }
+                        fl[q] = (unsigned)flag[q] | (it->second << 2);
+                    }
+                    if (uniq.empty()) uniq.resize(UCOL_PITCH, 0);
+                    HIPCHK(c, hipMalloc((void **)&c->ucol[d], uniq.size() * sizeof(uint16_t)));
+                    HIPCHK(c, hipMemcpy(c->ucol[d], uniq.data(), uniq.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+                    HIPCHK(c, hipMalloc((void **)&c->uflag[d], fl.size() * sizeof(unsigned)));
+                    HIPCHK(c, hipMemcpy(c->uflag[d], fl.data(), fl.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+                }
+            }
         }
     }
     for (int v = 0; v < 4; v++)
@@ -625,6 +686,7 @@ static void fill_params(fs3d_ctx *c, SweepParams<R> &p, int dir, double dt_, int
     p.node_ = (const R *)c->node; p.scr_ = (R *)c->scr; p.nstride = c->nstride;
     p.code = c->code;
     p.dead = c->dead[dir];
+    p.ucol = dir < 2 ? c->ucol[dir] : nullptr; p.uflag = dir < 2 ? c->uflag[dir] : nullptr; p.ung = (c->dimz + 31) / 32;
     // every constant below is evaluated in FTYPE exactly as the reference writes it
     const R dx = (R)c->gdx, dy = (R)c->gdy, dz = (R)c->gdz;          // TimeLayer3D.h:1078-1080
     const R ds = dir == 0 ? dx : (dir == 1 ? dy : dz);

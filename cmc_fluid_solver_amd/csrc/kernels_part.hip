@@ -155,6 +155,9 @@ __device__ __forceinline__ void part_step(R lead, R diag, R trail, R &cp, R &sp,
 // Measured (profiles/r3_ab_packed.txt, interleaved, bit-identical fields): Z kernel (226 of 256 VGPRs, no spills) 0.2111 -> 0.2022 ms;
 // X/Y kernels 0.254 -> 0.275 / 0.245 -> 0.271 -- they sit at their 128-VGPR budget and the even-aligned register pairs cost 16-21
 // spilled registers.  Packed in the Z kernel only.
+#ifndef FS3D_PART_UCOL
+#define FS3D_PART_UCOL 1              // shared code columns (SweepParams::ucol)
+#endif
 #ifndef FS3D_PART_PACKED_XY
 #define FS3D_PART_PACKED_XY 0
 #endif
@@ -290,10 +293,29 @@ __global__ void __launch_bounds__(LT * NCH, WPS) k_sweep_part(SweepParams<R> p, 
     unsigned inmask = 0, intmask = 0, segmask = 0;
     int cwv[M];
     {
+        // (r3) a group of lines that all carry the same codes reads ONE shared column (M codes = M/8 16-byte loads, the same
+        // addresses on all lanes of a chunk: cache hits) instead of M 2-byte loads per lane, 2 bytes per cell from HBM
+        bool tile_uni = false;
+        unsigned ucol_id = 0;
+        if (p.uflag && XB == 0 && FS3D_PART_UCOL != 0) {
+            const unsigned f = p.uflag[(long long)o * p.ung + tile_id * LT / 32];
+            tile_uni = LT == 64 ? (f & 2u) != 0 : (f & 1u) != 0;
+            ucol_id = f >> 2;
+        }
+        if (tile_uni) {
+            const pu32x4 *const col = (const pu32x4 *)(p.ucol + (long long)ucol_id * UCOL_PITCH + s0);
+#pragma unroll
+            for (int q4 = 0; q4 < M / 8; q4++) {
+                const pu32x4 w = col[q4];
+                cwv[8 * q4 + 0] = (int)(w.x & 0xFFFFu); cwv[8 * q4 + 1] = (int)(w.x >> 16); cwv[8 * q4 + 2] = (int)(w.y & 0xFFFFu); cwv[8 * q4 + 3] = (int)(w.y >> 16);
+                cwv[8 * q4 + 4] = (int)(w.z & 0xFFFFu); cwv[8 * q4 + 5] = (int)(w.z >> 16); cwv[8 * q4 + 6] = (int)(w.w & 0xFFFFu); cwv[8 * q4 + 7] = (int)(w.w >> 16);
+            }
+        } else {
         unsigned s_c = (son / (unsigned)sizeof(R)) * 2u;
         const unsigned ssc = (ssb / (unsigned)sizeof(R)) * 2u;
 #pragma unroll
         for (int i = 0; i < M; i++) { cwv[i] = __builtin_amdgcn_raw_buffer_load_b16(rCode, vel * 2u, s_c, 0); s_c = opq_s(s_c + ssc); }
+        }
     }
     // the first loads of the P phase do not depend on the codes: in flight before the codes are waited for (one memory
     // round trip less on the critical path of the workgroup)
