@@ -265,9 +265,9 @@ def main():
     for i in range(args.warmup):
         step(i)
     fence()
-    # HIP events around the kernel launches of the timed region -- of every 4th step: two events per launch cost a few microseconds
+    # HIP events around the kernel launches of the timed region -- of every 7th step (steps 0, 7, 14 of the default 20: 24 launches per sweep class): two events per launch cost a few microseconds
     # each (52 per step: measured 4-5 % of the step), the per-class averages need a sample, not every launch
-    s.enable_timing(int(os.environ.get("FS3D_BENCH_EVENT_PERIOD", "4")))
+    s.enable_timing(int(os.environ.get("FS3D_BENCH_EVENT_PERIOD", "7")))
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
@@ -351,7 +351,7 @@ def main():
                          "per_class_ms_per_launch": {nm: round(ms_cls[j] / max(1, n_cls[j]), 4)
                                                      for j, nm in enumerate(names + ["other"])},
                          "launches": dict(zip(names + ["other"], n_cls)),
-                         "launches_timed": "HIP events around the launches of every %s-th step of the timed region" % os.environ.get("FS3D_BENCH_EVENT_PERIOD", "4"),
+                         "launches_timed": "HIP events around the launches of every %s-th step of the timed region" % os.environ.get("FS3D_BENCH_EVENT_PERIOD", "7"),
                          "step_frac_of_hbm_roofline_1760B": round(
                              (cells * 1760.0 * (esize / 4) * args.steps / sec / 1e9) / (HBM_PEAK_GBS * world), 4),
                          "step_frac_of_hbm_roofline_moved": round(
